@@ -1,0 +1,183 @@
+/*
+ * mrisr.h — C-ABI of libmrisr.so, the MI355X (gfx950) kernel library behind the
+ * U-Net super-resolution hot path of rdd0582/mri_superresolution.
+ *
+ * The reference has no FFI boundary of its own: its "operator API" is the Python
+ * surface models/unet_model.py + utils/losses.py + the step loop of scripts/train.py,
+ * which dispatch into torch/aten.  Each entry point below
+ * replaces the aten ops one reference line (cited) dispatches; the Python mirror in
+ * mri_superresolution_amd/ binds them through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - ownership : every device buffer is allocated and owned by the caller (PyTorch);
+ *                the library never allocates persistent memory.
+ *  - errors    : every entry returns int (0 = ok, <0 = MRISR_E_*); mrisr_last_error()
+ *                returns a thread-local message.
+ *  - streams   : asynchronous launch on the caller's HIP stream (void* = hipStream_t),
+ *                no internal synchronisation, no global mutable state.
+ *  - layout    : activations NHWC ("channels last"), dtype MRISR_BF16 or MRISR_F32;
+ *                conv weights [Cout][kh][kw][Cin] fp32 masters (= torch channels_last
+ *                storage of a (Cout,Cin,kh,kw) tensor); statistics double / fp32.
+ */
+#ifndef MRISR_H
+#define MRISR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRISR_OK 0
+#define MRISR_E_ARG (-1)
+#define MRISR_E_SHAPE (-2)
+#define MRISR_E_DTYPE (-3)
+#define MRISR_E_HIP (-4)
+#define MRISR_E_UNSUPPORTED (-5)
+
+#define MRISR_F32 0
+#define MRISR_BF16 1
+
+/* source transform applied while a convolution loads its input (never materialised) */
+#define MRISR_SRC_RAW 0      /* value as stored                                              */
+#define MRISR_SRC_NORM 1     /* LeakyReLU(0.2)(x*scale[n,c]+shift[n,c]) = GroupNorm+act fused */
+#define MRISR_SRC_RELU 2     /* max(x,0) (VGG19 features)                                     */
+#define MRISR_SP_NONE 0
+#define MRISR_SP_POOL2 1     /* 2x2 max-pool of the transformed source  (unet_model.py:52)    */
+#define MRISR_SP_UP2 2       /* bilinear x2, align_corners=True         (unet_model.py:71,151)*/
+#define MRISR_COMBINE_CONCAT 0 /* torch.cat([src0, src1], 1)            (unet_model.py:93)    */
+#define MRISR_COMBINE_BLEND 1  /* sigmoid(a)*src0 + (1-sigmoid(a))*src1 (unet_model.py:206-7) */
+#define MRISR_OUT_PLAIN 0
+#define MRISR_OUT_PIXEL_SHUFFLE2 1 /* out[n,2y+i,2x+j,c/4] = conv[n,y,x,c], c=4c'+2i+j (unet_model.py:102) */
+
+typedef struct {
+    const void* ptr;     /* NHWC tensor [N][H][W][C] of the conv's dtype                       */
+    const float* scale;  /* [N][C] (MRISR_SRC_NORM) or NULL                                    */
+    const float* shift;  /* [N][C]                                                             */
+    int32_t C, H, W;     /* stored dims of this source                                         */
+    int32_t mode;        /* MRISR_SRC_*                                                        */
+    int32_t spatial;     /* MRISR_SP_*                                                         */
+    int32_t off_y, off_x;/* F.pad offsets of the source inside the conv input (unet_model.py:86-90) */
+} mrisr_src;
+
+typedef struct {
+    int32_t dtype;          /* MRISR_F32 | MRISR_BF16 (storage type of src/out/packed weights) */
+    int32_t N, H, W;        /* conv input (= output) spatial size                              */
+    int32_t Cin, Cout;
+    int32_t ksize;          /* 1 or 3 (padding ksize/2, stride 1)                              */
+    int32_t nsrc;           /* 1 or 2                                                          */
+    int32_t combine;        /* MRISR_COMBINE_*                                                 */
+    int32_t out_mode;       /* MRISR_OUT_*                                                     */
+    int32_t groups;         /* GroupNorm groups for the statistics epilogue (8), 0 = none      */
+    int32_t relu_out;       /* 1: store max(y,0) (VGG)                                         */
+    mrisr_src src[2];
+    const float* blend_alpha; /* device scalar (pre-sigmoid), MRISR_COMBINE_BLEND only         */
+    const void* wpacked;    /* from mrisr_pack_weights                                         */
+    const float* bias;      /* [Cout] or NULL                                                  */
+    void* out;              /* NHWC [N][H][W][Cout] (or pixel-shuffled [N][2H][2W][Cout/4])    */
+    double* stats;          /* [N][groups][2] running (sum, sum of squares), accumulated; or NULL */
+} mrisr_conv_desc;
+
+const char* mrisr_last_error(void);
+int mrisr_version(void);
+
+/* ---- convolution: replaces nn.Conv2d forward (unet_model.py:29,34,72,101,152,168) and, with
+ *      flipped/transposed packed weights and a RAW source, its input-gradient. ------------- */
+/* bytes of the packed image for a (Cout,Cin,k,k) weight */
+size_t mrisr_packed_weight_bytes(int dtype, int Cout, int Cin, int ksize);
+/* w: fp32 [Cout][k][k][Cin].  transpose_flip=0: forward operand; 1: dgrad operand
+ * (roles of Cin/Cout swapped, taps mirrored).                                              */
+int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, int ksize, int transpose_flip,
+                       void* packed, void* stream);
+int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream);
+/* weight gradient: dw[Cout][k][k][Cin] (fp32, ACCUMULATED) = sum_pix dy[pix][co] * in[pix+tap][ci];
+ * the input is described exactly as in the forward desc (d->out, d->wpacked, d->bias ignored). */
+int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, void* stream);
+
+/* stem conv Cin==1 (unet_model.py:29 for "inc"): x fp32 [N][H][W], w fp32 [Cout][9]          */
+int mrisr_stem_forward(int dtype, const float* x, const float* w, void* out, double* stats,
+                       int N, int H, int W, int Cout, int groups, void* stream);
+int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float* dw,
+                     int N, int H, int W, int Cout, void* stream);
+
+/* ---- GroupNorm(8,C)+LeakyReLU(0.2): statistics -> per-(n,c) affine (unet_model.py:30-31) -- */
+/* stats [N][G][2] double -> scale/shift [N][C] fp32, meanrstd [N][G][2] fp32; count = (C/G)*H*W */
+int mrisr_gn_finalize(const double* stats, const float* gamma, const float* beta, float* scale,
+                      float* shift, float* meanrstd, int N, int C, int groups, double count,
+                      float eps, void* stream);
+
+/* consumer of an activation in the backward pass */
+typedef struct {
+    const void* da;       /* NHWC gradient w.r.t. the consumer conv's (virtual) input           */
+    int32_t C_total;      /* channel stride of da                                               */
+    int32_t c_off;        /* first channel of this producer inside da                           */
+    int32_t H, W;         /* spatial dims of da                                                 */
+    int32_t spatial;      /* MRISR_SP_* that the consumer applied to this producer              */
+    int32_t off_y, off_x; /* pad offsets (MRISR_SP_NONE consumers)                              */
+    int32_t weight_mode;  /* 0: plain; 1: times sigmoid(alpha); 2: times 1-sigmoid(alpha)       */
+} mrisr_consumer;
+
+/* backward of LeakyReLU+GroupNorm for one producer tensor x [N][H][W][C] (raw conv output); restates
+ * aten leaky_relu_backward + native_group_norm_backward + the adjoints of max_pool2d / upsample_bilinear2d
+ * / cat / blend that autograd runs for unet_model.py:30-31,52,71,93,206-207.
+ *  reduce  : gathers dL/dact from up to 2 consumers, applies LeakyReLU', writes g = dL/d(gn out) (dtype)
+ *            and accumulates red[N][C][2] += (sum g, sum g*xhat) (fp32)
+ *  finalize: dgamma[C] += sum_n red[..][1], dbeta[C] += sum_n red[..][0], coef[3][N][C] such that
+ *            dx = g*coef0 + x*coef1 + coef2      (count = (C/groups)*H*W)
+ *  apply   : writes dx (dtype); out_mode PIXEL_SHUFFLE2 stores it un-shuffled as [N][H/2][W/2][4C].  */
+int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift,
+                         const float* meanrstd, int nconsumers, const mrisr_consumer* consumers,
+                         const float* blend_alpha, void* g, float* red, int N, int H, int W, int C,
+                         int groups, void* stream);
+int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* meanrstd, float* dgamma,
+                           float* dbeta, float* coef, int N, int C, int groups, double count, void* stream);
+int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N,
+                        int H, int W, int C, int out_mode, void* stream);
+/* out[C] += sum over pixels of x[npix][C]  (bias gradient of nn.Conv2d(bias=True), unet_model.py:101) */
+int mrisr_channel_sum(int dtype, const void* x, float* out, size_t npix, int C, void* stream);
+/* dalpha += sigmoid'(alpha) * sum da * (act0 - act1)   (unet_model.py:206-207)               */
+int mrisr_blend_alpha_grad(int dtype, const void* da, const void* x0, const float* scale0,
+                           const float* shift0, const void* x1, const float* scale1,
+                           const float* shift1, const float* alpha, float* dalpha, int N, int H,
+                           int W, int C, void* stream);
+
+/* ---- output head: GN+LReLU -> conv1x1(C->1)+bias -> sigmoid (unet_model.py:172,211) -------- */
+int mrisr_head_forward(int dtype, const void* x, const float* scale, const float* shift,
+                       const float* w, const float* b, float* out, int N, int H, int W, int C,
+                       void* stream);
+/* dout [N][H][W] fp32 -> da [N][H][W][C] (dtype), dw[C] and db (fp32, accumulated)           */
+int mrisr_head_backward(int dtype, const void* x, const float* scale, const float* shift,
+                        const float* w, const float* out, const float* dout, void* da, float* dw,
+                        float* db, int N, int H, int W, int C, void* stream);
+
+/* ---- loss: fused L1 + Gaussian-window SSIM (utils/losses.py:27-81,200-226) ---------------- */
+/* a, b: [N][H][W] fp32 (single channel), 11-tap window.  sums[N][2] (double, accumulated):
+ * sums[n][0] += sum|a-b|, sums[n][1] += sum ssim_map.  coef (optional, [3][N][H][W] fp32) receives
+ * dS/dmu1, dS/dE[x^2], dS/dE[xy] for the backward pass.                                        */
+int mrisr_ssim_l1_forward(const float* a, const float* b, double* sums, float* coef, int N, int H,
+                          int W, float val_range, float sigma, void* stream);
+/* da = gscale[0] * ( l1_w * sign(a-b) - ssim_w * [0<=mean ssim<=1] * d(sum ssim)/da ) / numel
+ * (gscale: device scalar, NULL = 1; sums NULL = no clamp mask, for the bare ssim() metric)       */
+int mrisr_ssim_l1_backward(const float* a, const float* b, const float* coef, const double* sums,
+                           const float* gscale, float l1_w, float ssim_w, float* da, int N, int H,
+                           int W, float sigma, void* stream);
+
+/* CombinedLoss scalar without the perceptual term (utils/losses.py:200-226): out[0] = l1_w*L1 +
+ * ssim_w*(1-clamp(SSIM,0,1)), out[1] = L1 mean, out[2] = SSIM mean, out[3+n] = per-sample SSIM.   */
+int mrisr_loss_finalize(const double* sums, int N, int H, int W, float l1_w, float ssim_w, float* out,
+                        void* stream);
+
+/* ---- optimiser: torch.optim.Adam with L2-coupled weight decay (scripts/train.py:186) ------- */
+/* grad_scale multiplies g first (1/world_size after a sum all-reduce).                        */
+int mrisr_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    void* stream);
+
+/* ---- layout helpers ----------------------------------------------------------------------- */
+int mrisr_cast(int src_dtype, const void* src, int dst_dtype, void* dst, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRISR_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libmrisr.so (include/mrisr.h).  No fallback: if the library is missing the
+import of anything that computes raises, so a GPU run can never silently use another path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrisr.so")
+
+F32, BF16 = 0, 1
+SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
+SP_NONE, SP_POOL2, SP_UP2 = 0, 1, 2
+COMBINE_CONCAT, COMBINE_BLEND = 0, 1
+OUT_PLAIN, OUT_PIXEL_SHUFFLE2 = 0, 1
+
+_vp, _fp, _dp, _i, _f, _d, _sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", _vp), ("scale", _fp), ("shift", _fp), ("C", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("mode", C.c_int32), ("spatial", C.c_int32), ("off_y", C.c_int32),
+                ("off_x", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cin", C.c_int32), ("Cout", C.c_int32), ("ksize", C.c_int32), ("nsrc", C.c_int32),
+                ("combine", C.c_int32), ("out_mode", C.c_int32), ("groups", C.c_int32),
+                ("relu_out", C.c_int32), ("src", Src * 2), ("blend_alpha", _fp), ("wpacked", _vp),
+                ("bias", _fp), ("out", _vp), ("stats", _dp)]
+
+
+class Consumer(C.Structure):
+    _fields_ = [("da", _vp), ("C_total", C.c_int32), ("c_off", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("spatial", C.c_int32), ("off_y", C.c_int32), ("off_x", C.c_int32),
+                ("weight_mode", C.c_int32)]
+
+
+# every symbol include/mrisr.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mrisr_last_error": (C.c_char_p, []),
+    "mrisr_version": (_i, []),
+    "mrisr_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
+    "mrisr_pack_weights": (_i, [_i, _fp, _i, _i, _i, _i, _vp, _vp]),
+    "mrisr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
+    "mrisr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _fp, _vp]),
+    "mrisr_stem_forward": (_i, [_i, _fp, _fp, _vp, _dp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_stem_wgrad": (_i, [_i, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),
+    "mrisr_gn_finalize": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _f, _vp]),
+    "mrisr_act_bwd_reduce": (_i, [_i, _vp, _fp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_act_bwd_finalize": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _vp]),
+    "mrisr_act_bwd_apply": (_i, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_channel_sum": (_i, [_i, _vp, _fp, _sz, _i, _vp]),
+    "mrisr_blend_alpha_grad": (_i, [_i, _vp, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mrisr_head_forward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mrisr_head_backward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mrisr_ssim_l1_forward": (_i, [_fp, _fp, _dp, _fp, _i, _i, _i, _f, _f, _vp]),
+    "mrisr_ssim_l1_backward": (_i, [_fp, _fp, _fp, _dp, _fp, _f, _f, _fp, _i, _i, _i, _f, _vp]),
+    "mrisr_loss_finalize": (_i, [_dp, _i, _i, _i, _f, _f, _fp, _vp]),
+    "mrisr_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "mrisr_cast": (_i, [_i, _vp, _i, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libmrisr.so (once).  Raises RuntimeError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. Run "
+            "`python -m mri_superresolution_amd.build` (needs hipcc); there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mrisr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libmrisr {what} failed ({rc}): {msg}")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,4 @@
+#include "common.h"
+thread_local char g_mrisr_err[512] = "";
+extern "C" const char* mrisr_last_error(void) { return g_mrisr_err; }
+extern "C" int mrisr_version(void) { return 100; }

@@ -1,0 +1,117 @@
+// Shared device/host helpers for libmrisr (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mrisr.h"
+
+// ---------------------------------------------------------------- errors (thread-local)
+extern thread_local char g_mrisr_err[512];
+#define MRISR_FAIL(code, ...)                                   \
+    do {                                                        \
+        snprintf(g_mrisr_err, sizeof(g_mrisr_err), __VA_ARGS__); \
+        return (code);                                          \
+    } while (0)
+#define MRISR_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) MRISR_FAIL(MRISR_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---------------------------------------------------------------- types
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LRELU_SLOPE 0.2f
+
+template <typename T> struct TypeTraits;
+template <> struct TypeTraits<float> {
+    static constexpr int kDtype = MRISR_F32;
+    static constexpr int kVec = 4;  // elements per 16-byte vector
+};
+template <> struct TypeTraits<bf16_t> {
+    static constexpr int kDtype = MRISR_BF16;
+    static constexpr int kVec = 8;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// A 16-byte register vector of T, with element access as float.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    f32x4 v;
+    static constexpr int N = 4;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+    __device__ __forceinline__ void zero() { v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+template <> struct Vec16<bf16_t> {
+    bf16x8 v;
+    static constexpr int N = 8;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+    __device__ __forceinline__ void zero() {
+        v = bf16x8{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f,
+                   (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> load_vec16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store_vec16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : LRELU_SLOPE * x; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {  // over the 32 lanes of each half
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bilinear x2 align_corners=True source coordinate, as aten's area_pixel_compute_source_index:
+// scale = (in-1)/(out-1) in float, src = scale*dst.
+__device__ __forceinline__ void up2_coord(int dst, int in_size, int& i0, int& i1, float& w1) {
+    const int out_size = 2 * in_size;
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    const float src = scale * (float)dst;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

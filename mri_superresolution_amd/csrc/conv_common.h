@@ -1,0 +1,281 @@
+// Shared pieces of the implicit-GEMM convolution kernels (forward/dgrad and wgrad):
+// the fused input loader (GroupNorm+LeakyReLU apply, 2x2 max-pool, bilinear x2, concat, blend)
+// and the LDS image conventions.
+#pragma once
+#include "common.h"
+
+constexpr int kConvThreads = 256;   // 4 waves
+constexpr int kRowBytes = 64;       // bytes of K (input channels) per LDS row and cin-chunk
+constexpr int kMaxHaloIter = 6;     // ceil(340 / 64): tiles 8x32, 16x16, 32x8 (+halo)
+
+// LDS rows are 64 B = four 16-B chunks; chunk c of row r lives at chunk position c ^ swz(r), which
+// makes the MFMA fragment reads (ds_read_b128, 32 consecutive rows, same chunk) conflict-free.
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * kRowBytes + ((chunk ^ swz(row)) << 4);
+}
+
+static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
+static inline int conv_bk(int dtype) { return dtype == MRISR_BF16 ? 32 : 16; }
+
+struct SrcDev {
+    const void* ptr;
+    const float* scale;
+    const float* shift;
+    int C, H, W, mode, off_y, off_x;
+};
+
+struct ConvParams {
+    SrcDev src[2];
+    const float* blend_alpha;
+    const void* wpacked;
+    const float* bias;
+    void* out;
+    double* stats;
+    const void* dy;   // wgrad only
+    float* dw;        // wgrad only
+    int N, H, W, Cin, CinP, Cout, CoutP;
+    int nsrc, combine, out_mode, groups, relu_out;
+    int tw_log2, th, tiles_x, tiles_y, ncb, nchunks;
+    int ksplit;       // wgrad only
+};
+
+// Per-thread precomputed geometry of the halo pixels this thread stages (same for every cin chunk).
+template <int SPATIAL> struct HaloGeom;
+template <> struct HaloGeom<MRISR_SP_NONE> {
+    int off0[kMaxHaloIter];   // element offset into src0 (without channel), -1 = zero
+    int off1[kMaxHaloIter];   // same for src1 (concat / blend)
+};
+template <> struct HaloGeom<MRISR_SP_POOL2> {
+    int off0[kMaxHaloIter];
+};
+template <> struct HaloGeom<MRISR_SP_UP2> {
+    int off0[kMaxHaloIter];
+    int dyo[kMaxHaloIter], dxo[kMaxHaloIter];
+    float wy[kMaxHaloIter], wx[kMaxHaloIter];
+};
+
+template <typename T>
+__device__ __forceinline__ void transform_vec(Vec16<T>& v, int mode, const float* sc, const float* sh) {
+    if (mode == MRISR_SRC_NORM) {
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) v.set(e, lrelu(v.get(e) * sc[e] + sh[e]));
+    } else if (mode == MRISR_SRC_RELU) {
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) v.set(e, fmaxf(v.get(e), 0.f));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void transform_f(const Vec16<T>& v, float* o, int mode, const float* sc,
+                                            const float* sh) {
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) {
+        float x = v.get(e);
+        if (mode == MRISR_SRC_NORM) x = lrelu(x * sc[e] + sh[e]);
+        else if (mode == MRISR_SRC_RELU) x = fmaxf(x, 0.f);
+        o[e] = x;
+    }
+}
+
+// Computes the geometry of halo pixel `hp` of the tile at (n, ty0, tx0); halo width hw, conv padding pad.
+template <int SPATIAL>
+__device__ __forceinline__ void halo_geom_init(HaloGeom<SPATIAL>& g, int i, int hp, int npix_halo, int hw,
+                                               int pad, int n, int ty0, int tx0, const ConvParams& p) {
+    int o0 = -1;
+    const int hy = hp / hw, hx = hp - hy * hw;
+    const int y = ty0 + hy - pad, x = tx0 + hx - pad;
+    const bool inside = hp < npix_halo && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const SrcDev& s0 = p.src[0];
+    if constexpr (SPATIAL == MRISR_SP_NONE) {
+        int o1 = -1;
+        if (inside) {
+            const int ys = y - s0.off_y, xs = x - s0.off_x;
+            if (ys >= 0 && ys < s0.H && xs >= 0 && xs < s0.W) o0 = ((n * s0.H + ys) * s0.W + xs) * s0.C;
+            if (p.nsrc > 1) {
+                const SrcDev& s1 = p.src[1];
+                const int y1 = y - s1.off_y, x1 = x - s1.off_x;
+                if (y1 >= 0 && y1 < s1.H && x1 >= 0 && x1 < s1.W) o1 = ((n * s1.H + y1) * s1.W + x1) * s1.C;
+            }
+        }
+        g.off0[i] = o0;
+        g.off1[i] = o1;
+    } else if constexpr (SPATIAL == MRISR_SP_POOL2) {
+        if (inside) o0 = ((n * s0.H + 2 * y) * s0.W + 2 * x) * s0.C;
+        g.off0[i] = o0;
+    } else {
+        int dyo = 0, dxo = 0;
+        float wy = 0.f, wx = 0.f;
+        if (inside) {
+            const int ys = y - s0.off_y, xs = x - s0.off_x;
+            if (ys >= 0 && ys < 2 * s0.H && xs >= 0 && xs < 2 * s0.W) {
+                int y0, y1, x0, x1;
+                up2_coord(ys, s0.H, y0, y1, wy);
+                up2_coord(xs, s0.W, x0, x1, wx);
+                o0 = ((n * s0.H + y0) * s0.W + x0) * s0.C;
+                dyo = (y1 - y0) * s0.W * s0.C;
+                dxo = (x1 - x0) * s0.C;
+            }
+        }
+        g.off0[i] = o0;
+        g.dyo[i] = dyo;
+        g.dxo[i] = dxo;
+        g.wy[i] = wy;
+        g.wx[i] = wx;
+    }
+}
+
+// Loads + transforms the 16-byte channel vector [c0, c0+VEC) of halo pixel slot i.
+template <typename T, int SPATIAL>
+__device__ __forceinline__ Vec16<T> halo_load(const HaloGeom<SPATIAL>& g, int i, int c0, const ConvParams& p,
+                                              const float* sc0, const float* sh0, const float* sc1,
+                                              const float* sh1, float blend_a, int which_src, int cs) {
+    constexpr int VEC = Vec16<T>::N;
+    Vec16<T> out;
+    out.zero();
+    if constexpr (SPATIAL == MRISR_SP_NONE) {
+        if (p.combine == MRISR_COMBINE_BLEND) {
+            const int o0 = g.off0[i], o1 = g.off1[i];
+            if (o0 >= 0 && o1 >= 0) {   // both sources share the conv geometry
+                Vec16<T> a = load_vec16((const T*)p.src[0].ptr + o0 + c0);
+                Vec16<T> b = load_vec16((const T*)p.src[1].ptr + o1 + c0);
+                float fa[VEC], fb[VEC];
+                transform_f(a, fa, p.src[0].mode, sc0, sh0);
+                transform_f(b, fb, p.src[1].mode, sc1, sh1);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) out.set(e, blend_a * fa[e] + (1.f - blend_a) * fb[e]);
+            }
+        } else {
+            const int o = which_src ? g.off1[i] : g.off0[i];
+            if (o >= 0 && cs >= 0) {
+                out = load_vec16((const T*)p.src[which_src].ptr + o + cs);
+                transform_vec(out, p.src[which_src].mode, which_src ? sc1 : sc0, which_src ? sh1 : sh0);
+            }
+        }
+    } else if constexpr (SPATIAL == MRISR_SP_POOL2) {
+        const int o = g.off0[i];
+        if (o >= 0 && cs >= 0) {
+            const T* b = (const T*)p.src[0].ptr + o + cs;
+            const int rs = p.src[0].W * p.src[0].C;
+            Vec16<T> v00 = load_vec16(b), v01 = load_vec16(b + p.src[0].C);
+            Vec16<T> v10 = load_vec16(b + rs), v11 = load_vec16(b + rs + p.src[0].C);
+            float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+            transform_f(v00, f00, p.src[0].mode, sc0, sh0);
+            transform_f(v01, f01, p.src[0].mode, sc0, sh0);
+            transform_f(v10, f10, p.src[0].mode, sc0, sh0);
+            transform_f(v11, f11, p.src[0].mode, sc0, sh0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) out.set(e, fmaxf(fmaxf(f00[e], f01[e]), fmaxf(f10[e], f11[e])));
+        }
+    } else {
+        const int o = g.off0[i];
+        if (o >= 0 && cs >= 0) {
+            const T* b = (const T*)p.src[0].ptr + o + cs;
+            Vec16<T> v00 = load_vec16(b), v01 = load_vec16(b + g.dxo[i]);
+            Vec16<T> v10 = load_vec16(b + g.dyo[i]), v11 = load_vec16(b + g.dyo[i] + g.dxo[i]);
+            float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+            transform_f(v00, f00, p.src[0].mode, sc0, sh0);
+            transform_f(v01, f01, p.src[0].mode, sc0, sh0);
+            transform_f(v10, f10, p.src[0].mode, sc0, sh0);
+            transform_f(v11, f11, p.src[0].mode, sc0, sh0);
+            const float wy1 = g.wy[i], wx1 = g.wx[i], wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)   // aten upsample_bilinear2d: l0*(w0*a+w1*b) + l1*(w0*c+w1*d)
+                out.set(e, wy0 * (wx0 * f00[e] + wx1 * f01[e]) + wy1 * (wx0 * f10[e] + wx1 * f11[e]));
+        }
+    }
+    return out;
+}
+
+// Loads scale/shift vectors for channel vector c (source s) of image n; fills 1/0 when not NORM.
+template <int VEC>
+__device__ __forceinline__ void load_affine(const SrcDev& s, int n, int c, float* sc, float* sh) {
+    if (s.mode == MRISR_SRC_NORM && c >= 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s.scale + (size_t)n * s.C + c + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(s.shift + (size_t)n * s.C + c + e);
+            sc[e] = a[0]; sc[e + 1] = a[1]; sc[e + 2] = a[2]; sc[e + 3] = a[3];
+            sh[e] = b[0]; sh[e + 1] = b[1]; sh[e + 2] = b[2]; sh[e + 3] = b[3];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    }
+}
+
+// wgrad LDS rows are 128 B (two 64-B cin sub-chunks); the 64-B halves of a row are exchanged on
+// every other row pair so that the transposed fragment reads (4 consecutive rows x 64 B per
+// 32-lane half) cover all 64 banks.
+__device__ __forceinline__ int lds_off128(int row, int sub, int chunk) {
+    return row * 128 + ((sub ^ ((row >> 1) & 1)) << 6) + (chunk << 4);
+}
+
+// Stages the transformed halo tile of cin chunk kc into LDS (rows = halo pixels; ROWB = 64: forward
+// image, ROWB = 128: wgrad image, `sub` selects the 64-B half).
+template <typename T, int SPATIAL, int ROWB = 64, int BATCH = kMaxHaloIter>
+__device__ __forceinline__ void stage_halo(char* lds_halo, const HaloGeom<SPATIAL>& g, int kc, int n,
+                                           int npix_halo, float blend_a, const ConvParams& p, int sub = 0) {
+    constexpr int VEC = Vec16<T>::N;
+    const int t = threadIdx.x;
+    const int chunk = t & 3;
+    const int c0 = kc * (kRowBytes / (int)sizeof(T)) + chunk * VEC;   // channel in the conv input
+    int which = 0, cs = c0;
+    if (p.combine == MRISR_COMBINE_CONCAT) {
+        if (p.nsrc > 1 && c0 >= p.src[0].C) { which = 1; cs = c0 - p.src[0].C; }
+        if (cs >= p.src[which].C) cs = -1;     // zero padding of Cin up to CinP
+    } else if (c0 >= p.src[0].C) {
+        cs = -1;
+    }
+    float sc0[VEC], sh0[VEC], sc1[VEC], sh1[VEC];
+    if constexpr (SPATIAL != MRISR_SP_NONE) {      // single-source kernels
+        load_affine<VEC>(p.src[0], n, cs, sc0, sh0);
+#pragma unroll
+        for (int i = 0; i < kMaxHaloIter; ++i) {
+            const int hp = (t >> 2) + 64 * i;
+            const Vec16<T> v = halo_load<T, SPATIAL>(g, i, c0, p, sc0, sh0, sc0, sh0, blend_a, 0, cs);
+            if (hp < npix_halo)
+                *reinterpret_cast<decltype(v.v)*>(
+                    lds_halo + (ROWB == 64 ? lds_off(hp, chunk) : lds_off128(hp, sub, chunk))) = v.v;
+            __builtin_amdgcn_sched_barrier(0);   // one gather (4 loads) in flight: keeps VGPRs for the accumulators
+        }
+        return;
+    } else {
+        if (p.combine == MRISR_COMBINE_BLEND) {
+            load_affine<VEC>(p.src[0], n, cs, sc0, sh0);
+            load_affine<VEC>(p.src[1], n, cs, sc1, sh1);
+        } else if (which == 0) {
+            load_affine<VEC>(p.src[0], n, cs, sc0, sh0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sc1[e] = 1.f; sh1[e] = 0.f; }
+        } else {
+            load_affine<VEC>(p.src[1], n, cs, sc1, sh1);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { sc0[e] = 1.f; sh0[e] = 0.f; }
+        }
+        const bool blend_dead = (p.combine == MRISR_COMBINE_BLEND && cs < 0);
+#pragma unroll
+        for (int i0 = 0; i0 < kMaxHaloIter; i0 += BATCH) {   // BATCH gathers in flight at a time
+            Vec16<T> vals[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (blend_dead || i0 + j >= kMaxHaloIter) vals[j].zero();
+                else vals[j] = halo_load<T, SPATIAL>(g, i0 + j, c0, p, sc0, sh0, sc1, sh1, blend_a, which, cs);
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int hp = (t >> 2) + 64 * (i0 + j);
+                if (i0 + j < kMaxHaloIter && hp < npix_halo)
+                    *reinterpret_cast<decltype(vals[j].v)*>(
+                        lds_halo + (ROWB == 64 ? lds_off(hp, chunk) : lds_off128(hp, sub, chunk))) = vals[j].v;
+            }
+            if (BATCH < kMaxHaloIter) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// tile shape for a W-wide image: TH*TW = 256
+static inline void conv_choose_tile(int W, int& th, int& tw_log2) {
+    if (W > 16) { tw_log2 = 5; th = 8; }
+    else if (W > 8) { tw_log2 = 4; th = 16; }
+    else { tw_log2 = 3; th = 32; }
+}

@@ -1,0 +1,251 @@
+// The two single-channel ends of the U-Net, which have no MFMA-shaped contraction and are HBM-bound:
+//   stem  : nn.Conv2d(1, f, 3, padding=1, bias=False)                   (unet_model.py:29 for `inc`)
+//   head  : GroupNorm+LeakyReLU -> nn.Conv2d(f/2, 1, 1) + bias -> sigmoid (unet_model.py:169-172, 211)
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ stem
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       T* __restrict__ out, double* __restrict__ stats, int H, int W,
+                                                       int Cout, int groups, int pix_per_block) {
+    constexpr int VEC = Vec16<T>::N;
+    extern __shared__ float sm[];            // [Cout*9] weights, then [groups*2] statistics
+    float* sw = sm;
+    float* sst = sm + Cout * 9;
+    const int t = threadIdx.x, n = blockIdx.y;
+    for (int i = t; i < Cout * 9; i += 256) sw[i] = w[i];
+    for (int i = t; i < groups * 2; i += 256) sst[i] = 0.f;
+    __syncthreads();
+    const int nvec = Cout / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    const int HW = H * W, gs = groups > 0 ? Cout / groups : Cout;
+    const float* xb = x + (size_t)n * HW;
+    float s[VEC], ss[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    if (pl < ppb)
+        for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+            const int y = pix / W, xx = pix - y * W;
+            float in[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int yy = y + r - 1, xq = xx + q - 1;
+                    in[r * 3 + q] = (yy >= 0 && yy < H && xq >= 0 && xq < W) ? xb[yy * W + xq] : 0.f;
+                }
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a += in[k] * sw[(c + e) * 9 + k];
+                o.set(e, a);
+                const float q = o.get(e);
+                s[e] += q;
+                ss[e] += q * q;
+            }
+            store_vec16(out + ((size_t)n * HW + pix) * Cout + c, o);
+        }
+    if (stats) {
+        if (pl < ppb) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                atomicAdd(&sst[2 * ((c + e) / gs)], s[e]);
+                atomicAdd(&sst[2 * ((c + e) / gs) + 1], ss[e]);
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < groups * 2; i += 256) atomic_add_f64(&stats[(size_t)n * groups * 2 + i], (double)sst[i]);
+    }
+}
+
+extern "C" int mrisr_stem_forward(int dtype, const float* x, const float* w, void* out, double* stats, int N, int H,
+                                  int W, int Cout, int groups, void* stream) {
+    if (!x || !w || !out) MRISR_FAIL(MRISR_E_ARG, "stem_forward: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (Cout % vec || Cout / vec > 256 || (stats && (groups <= 0 || Cout % groups))) MRISR_FAIL(MRISR_E_SHAPE, "stem_forward: Cout %d", Cout);
+    const int ppb = 256 / (Cout / vec);
+    int ppblk = ppb * 8;
+    dim3 grid(ceil_div(H * W, ppblk), N);
+    const size_t lds = (size_t)(Cout * 9 + (groups > 0 ? groups : 0) * 2) * sizeof(float);
+    if (dtype == MRISR_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, H, W, Cout, groups, ppblk);
+    else if (dtype == MRISR_F32) stem_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (float*)out, stats, H, W, Cout, groups, ppblk);
+    else MRISR_FAIL(MRISR_E_DTYPE, "stem_forward: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("stem_forward");
+    return MRISR_OK;
+}
+
+// dw[co][tap] += sum_{n,y,x} dy[n,y,x,co] * x[n,y+r-1,x+s-1]
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                         float* __restrict__ dw, int H, int W, int Cout, int pix_per_block) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float lds[256 * 9];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = Cout / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    const int HW = H * W;
+    const float* xb = x + (size_t)n * HW;
+    float acc[VEC][9];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[e][k] = 0.f;
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    if (pl < ppb)
+        for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+            const int y = pix / W, xx = pix - y * W;
+            float in[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int yy = y + r - 1, xq = xx + q - 1;
+                    in[r * 3 + q] = (yy >= 0 && yy < H && xq >= 0 && xq < W) ? xb[yy * W + xq] : 0.f;
+                }
+            const Vec16<T> d = load_vec16(dy + ((size_t)n * HW + pix) * Cout + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[e][k] += d.get(e) * in[k];
+        }
+    // reduce over pixel lanes, one output channel element at a time (keeps LDS small)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lds[t * 9 + k] = (pl < ppb) ? acc[e][k] : 0.f;
+        __syncthreads();
+        for (int i = t; i < nvec * 9; i += 256) {
+            const int cvj = i / 9, k = i - cvj * 9;
+            float a = 0.f;
+            for (int q = 0; q < ppb; ++q) a += lds[(q * nvec + cvj) * 9 + k];
+            atomic_add_f32(&dw[(cvj * VEC + e) * 9 + k], a);
+        }
+    }
+}
+
+extern "C" int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float* dw, int N, int H, int W, int Cout,
+                                void* stream) {
+    if (!x || !dy || !dw) MRISR_FAIL(MRISR_E_ARG, "stem_wgrad: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (Cout % vec || Cout / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "stem_wgrad: Cout %d", Cout);
+    const int ppb = 256 / (Cout / vec);
+    const int ppblk = ppb * 64;
+    dim3 grid(ceil_div(H * W, ppblk), N);
+    if (dtype == MRISR_BF16) stem_wgrad_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dy, dw, H, W, Cout, ppblk);
+    else if (dtype == MRISR_F32) stem_wgrad_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(x, (const float*)dy, dw, H, W, Cout, ppblk);
+    else MRISR_FAIL(MRISR_E_DTYPE, "stem_wgrad: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("stem_wgrad");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ head
+// thread = pixel; channels looped (C <= 128)
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ out, int HW, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    extern __shared__ float sm[];   // scale[C], shift[C], w[C]
+    const int n = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < C; i += 256) {
+        sm[i] = scale[(size_t)n * C + i];
+        sm[C + i] = shift[(size_t)n * C + i];
+        sm[2 * C + i] = w[i];
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + t;
+    if (pix >= HW) return;
+    const T* px = x + ((size_t)n * HW + pix) * C;
+    float z = b[0];
+    for (int c = 0; c < C; c += VEC) {
+        const Vec16<T> v = load_vec16(px + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) z += lrelu(v.get(e) * sm[c + e] + sm[C + c + e]) * sm[2 * C + c + e];
+    }
+    out[(size_t)n * HW + pix] = 1.f / (1.f + __expf(-z));
+}
+
+extern "C" int mrisr_head_forward(int dtype, const void* x, const float* scale, const float* shift, const float* w,
+                                  const float* b, float* out, int N, int H, int W, int C, void* stream) {
+    if (!x || !scale || !shift || !w || !b || !out) MRISR_FAIL(MRISR_E_ARG, "head_forward: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "head_forward: C %d", C);
+    dim3 grid(ceil_div(H * W, 256), N);
+    const size_t lds = 3 * C * sizeof(float);
+    if (dtype == MRISR_BF16) head_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, w, b, out, H * W, C);
+    else if (dtype == MRISR_F32) head_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)x, scale, shift, w, b, out, H * W, C);
+    else MRISR_FAIL(MRISR_E_DTYPE, "head_forward: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("head_forward");
+    return MRISR_OK;
+}
+
+// dz = dout * out * (1-out);  da[c] = dz * w[c];  dw[c] += sum dz * act[c];  db += sum dz
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ w,
+                                                       const float* __restrict__ out, const float* __restrict__ dout,
+                                                       T* __restrict__ da, float* __restrict__ dw, float* __restrict__ db,
+                                                       int HW, int C, int pix_per_block) {
+    constexpr int VEC = Vec16<T>::N;
+    extern __shared__ float sm[];   // scale[C], shift[C], w[C], dwacc[C], dbacc
+    const int n = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < C; i += 256) {
+        sm[i] = scale[(size_t)n * C + i];
+        sm[C + i] = shift[(size_t)n * C + i];
+        sm[2 * C + i] = w[i];
+        sm[3 * C + i] = 0.f;
+    }
+    if (t == 0) sm[4 * C] = 0.f;
+    __syncthreads();
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    float dbs = 0.f;
+    for (int c = 0; c < C; c += VEC) {           // channel-vector outer loop keeps dw partials in VEC registers
+        float dws[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dws[e] = 0.f;
+        for (int pix = blockIdx.x * pix_per_block + t; pix < pend; pix += 256) {
+            const size_t gp = (size_t)n * HW + pix;
+            const float o = out[gp];
+            const float dz = dout[gp] * o * (1.f - o);
+            if (c == 0) dbs += dz;
+            const Vec16<T> v = load_vec16(x + gp * C + c);
+            Vec16<T> g;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                dws[e] += dz * lrelu(v.get(e) * sm[c + e] + sm[C + c + e]);
+                g.set(e, dz * sm[2 * C + c + e]);
+            }
+            store_vec16(da + gp * C + c, g);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float r = wave_sum(dws[e]);
+            if ((t & 63) == 0) atomicAdd(&sm[3 * C + c + e], r);
+        }
+    }
+    dbs = wave_sum(dbs);
+    if ((t & 63) == 0) atomicAdd(&sm[4 * C], dbs);
+    __syncthreads();
+    for (int i = t; i < C; i += 256) atomic_add_f32(&dw[i], sm[3 * C + i]);
+    if (t == 0) atomic_add_f32(db, sm[4 * C]);
+}
+
+extern "C" int mrisr_head_backward(int dtype, const void* x, const float* scale, const float* shift, const float* w,
+                                   const float* out, const float* dout, void* da, float* dw, float* db, int N, int H,
+                                   int W, int C, void* stream) {
+    if (!x || !scale || !shift || !w || !out || !dout || !da || !dw || !db) MRISR_FAIL(MRISR_E_ARG, "head_backward: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "head_backward: C %d", C);
+    const int ppblk = 256 * 8;
+    dim3 grid(ceil_div(H * W, ppblk), N);
+    const size_t lds = (4 * C + 1) * sizeof(float);
+    if (dtype == MRISR_BF16) head_bwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, w, out, dout, (bf16_t*)da, dw, db, H * W, C, ppblk);
+    else if (dtype == MRISR_F32) head_bwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)x, scale, shift, w, out, dout, (float*)da, dw, db, H * W, C, ppblk);
+    else MRISR_FAIL(MRISR_E_DTYPE, "head_backward: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("head_backward");
+    return MRISR_OK;
+}

@@ -1,0 +1,441 @@
+// GroupNorm(8,C)+LeakyReLU(0.2) support kernels (HBM-bound element-wise / reduction passes).
+//
+// Forward: the convolution epilogue accumulates per-(n,group) sums; gn_finalize turns them into the
+// per-(n,c) affine (scale, shift) that consumer convolutions apply while loading
+// (/root/reference/models/unet_model.py:30-31 and siblings).
+// Backward: aten native_group_norm_backward + leaky_relu_backward + the adjoints of max-pool,
+// bilinear upsample, concat and blend, restated as
+//   pass 1 (act_bwd_reduce)   g = LeakyReLU'(.) * sum_consumers dL/dact ;  red[n][c] = (sum g, sum g*xhat)
+//   finalize                  dgamma, dbeta, and per-(n,c) coefficients A, B, C
+//   pass 2 (act_bwd_apply)    dx = g*A + x*B + C
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ void gn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ meanrstd, int N, int C,
+                                   int groups, double count, float eps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * C) return;
+    const int n = idx / C, c = idx - n * C;
+    const int gs = C / groups, g = c / gs;
+    const double s = stats[((size_t)n * groups + g) * 2], ss = stats[((size_t)n * groups + g) * 2 + 1];
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float m = (float)mean;
+    const float sc = gamma[c] * rstd;
+    scale[idx] = sc;
+    shift[idx] = beta[c] - m * sc;
+    if (c == g * gs) {
+        meanrstd[((size_t)n * groups + g) * 2] = m;
+        meanrstd[((size_t)n * groups + g) * 2 + 1] = rstd;
+    }
+}
+
+extern "C" int mrisr_gn_finalize(const double* stats, const float* gamma, const float* beta, float* scale,
+                                 float* shift, float* meanrstd, int N, int C, int groups, double count,
+                                 float eps, void* stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || !meanrstd) MRISR_FAIL(MRISR_E_ARG, "gn_finalize: null pointer");
+    if (groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "gn_finalize: C %d groups %d", C, groups);
+    gn_finalize_kernel<<<ceil_div(N * C, 256), 256, 0, (hipStream_t)stream>>>(stats, gamma, beta, scale, shift,
+                                                                             meanrstd, N, C, groups, count, eps);
+    MRISR_CHECK_LAUNCH("gn_finalize");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ConsumerDev {
+    const void* da;
+    int C_total, c_off, H, W, spatial, off_y, off_x, weight_mode;
+};
+struct ActBwdParams {
+    const void* x;
+    const float* scale;
+    const float* shift;
+    const float* meanrstd;
+    const float* blend_alpha;
+    void* g;
+    float* red;      // [N][C][2]
+    ConsumerDev cons[2];
+    int ncons, N, H, W, C, groups, pix_per_block;
+};
+
+template <typename T>
+__device__ __forceinline__ void act_of(const T* p, const float* sc, const float* sh, float* o) {
+    const Vec16<T> v = load_vec16(p);
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) o[e] = lrelu(v.get(e) * sc[e] + sh[e]);
+}
+
+// candidate high-res rows of a bilinear x2 (align_corners) adjoint and their weights for low-res index y
+__device__ __forceinline__ void up2_adjoint_weights(int y, int in_size, int* idx, float* w) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int Y = 2 * y - 2 + k;
+        float wt = 0.f;
+        if (Y >= 0 && Y < 2 * in_size) {
+            int i0, i1;
+            float w1;
+            up2_coord(Y, in_size, i0, i1, w1);
+            if (i0 == y) wt += 1.f - w1;
+            if (i1 == y) wt += w1;
+        }
+        idx[k] = Y;
+        w[k] = wt;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams p) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float lds[256 * VEC * 2];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = p.C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec;
+    const bool active = pl < ppb;
+    const int c = cv * VEC;
+    const int HW = p.H * p.W;
+    const int gs = p.C / p.groups;
+
+    float sc[VEC], sh[VEC], sA[VEC], sB[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = p.scale[(size_t)n * p.C + c + e];
+        sh[e] = p.shift[(size_t)n * p.C + c + e];
+        sA[e] = 0.f;
+        sB[e] = 0.f;
+    }
+    float mean[VEC], rstd[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (c + e) / gs;
+        mean[e] = p.meanrstd[((size_t)n * p.groups + g) * 2];
+        rstd[e] = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
+    }
+    float bw[3] = {1.f, 1.f, 1.f};
+    if (p.blend_alpha) {
+        const float a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
+        bw[1] = a;
+        bw[2] = 1.f - a;
+    }
+    const T* xb = (const T*)p.x + (size_t)n * HW * p.C;
+    T* gb = (T*)p.g + (size_t)n * HW * p.C;
+    const int pix_end = min(HW, (int)(blockIdx.x + 1) * p.pix_per_block);
+    if (active) {
+        for (int pix = blockIdx.x * p.pix_per_block + pl; pix < pix_end; pix += ppb) {
+            const int y = pix / p.W, x = pix - y * p.W;
+            const Vec16<T> xv = load_vec16(xb + (size_t)pix * p.C + c);
+            float gact[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gact[e] = 0.f;
+            for (int k = 0; k < p.ncons; ++k) {
+                const ConsumerDev& cs = p.cons[k];
+                const T* dab = (const T*)cs.da + (size_t)n * cs.H * cs.W * cs.C_total + cs.c_off + c;
+                const float wgt = bw[cs.weight_mode];
+                if (cs.spatial == MRISR_SP_NONE) {
+                    const int yy = y + cs.off_y, xx = x + cs.off_x;
+                    if (yy < cs.H && xx < cs.W) {
+                        const Vec16<T> d = load_vec16(dab + ((size_t)yy * cs.W + xx) * cs.C_total);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
+                    }
+                } else if (cs.spatial == MRISR_SP_POOL2) {
+                    const int py = y >> 1, px = x >> 1;
+                    if (py < cs.H && px < cs.W) {
+                        // recompute the 2x2 window's activations; the first maximum in scan order wins
+                        float a[4][VEC];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            act_of<T>(xb + ((size_t)(2 * py + (q >> 1)) * p.W + 2 * px + (q & 1)) * p.C + c, sc, sh, a[q]);
+                        const int me = ((y & 1) << 1) | (x & 1);
+                        const Vec16<T> d = load_vec16(dab + ((size_t)py * cs.W + px) * cs.C_total);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            int win = 0;
+                            float m = a[0][e];
+#pragma unroll
+                            for (int q = 1; q < 4; ++q)
+                                if (a[q][e] > m) { m = a[q][e]; win = q; }
+                            if (win == me) gact[e] += wgt * d.get(e);
+                        }
+                    }
+                } else {   // adjoint of bilinear x2 (align_corners=True)
+                    int iy[6], ix[6];
+                    float wy[6], wx[6];
+                    up2_adjoint_weights(y, p.H, iy, wy);
+                    up2_adjoint_weights(x, p.W, ix, wx);
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        if (wy[a] == 0.f) continue;
+#pragma unroll
+                        for (int b = 0; b < 6; ++b) {
+                            if (wx[b] == 0.f) continue;
+                            const int yy = iy[a] + cs.off_y, xx = ix[b] + cs.off_x;
+                            const Vec16<T> d = load_vec16(dab + ((size_t)yy * cs.W + xx) * cs.C_total);
+                            const float wv = wgt * wy[a] * wx[b];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) gact[e] += wv * d.get(e);
+                        }
+                    }
+                }
+            }
+            Vec16<T> gv;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xr = xv.get(e);
+                const float pre = xr * sc[e] + sh[e];
+                const float gy = gact[e] * (pre > 0.f ? 1.f : LRELU_SLOPE);
+                gv.set(e, gy);
+                const float gq = gv.get(e);                 // the rounded value pass 2 will read
+                sA[e] += gq;
+                sB[e] += gq * ((xr - mean[e]) * rstd[e]);
+            }
+            store_vec16(gb + (size_t)pix * p.C + c, gv);
+        }
+    }
+    // block reduction over the pixel lanes that share a channel vector
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        lds[(t * VEC + e) * 2] = active ? sA[e] : 0.f;
+        lds[(t * VEC + e) * 2 + 1] = active ? sB[e] : 0.f;
+    }
+    __syncthreads();
+    for (int i = t; i < nvec * VEC * 2; i += 256) {
+        const int j = i >> 1, which = i & 1;
+        const int cvj = j / VEC, e = j - cvj * VEC;
+        float s = 0.f;
+        for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
+        atomic_add_f32(&p.red[((size_t)n * p.C + cvj * VEC + e) * 2 + which], s);
+    }
+}
+
+extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift,
+                                    const float* meanrstd, int nconsumers, const mrisr_consumer* consumers,
+                                    const float* blend_alpha, void* g, float* red, int N, int H, int W, int C,
+                                    int groups, void* stream) {
+    if (!x || !scale || !shift || !meanrstd || !g || !red || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: null pointer");
+    if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: %d consumers", nconsumers);
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec || C / vec > 256 || groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: C %d", C);
+    ActBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.scale = scale; p.shift = shift; p.meanrstd = meanrstd; p.blend_alpha = blend_alpha; p.g = g; p.red = red;
+    p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C; p.groups = groups;
+    for (int k = 0; k < nconsumers; ++k) {
+        const mrisr_consumer& c = consumers[k];
+        if (!c.da) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: consumer %d null", k);
+        if (c.weight_mode < 0 || c.weight_mode > 2 || (c.weight_mode && !blend_alpha)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: weight_mode");
+        if (c.c_off % vec || c.C_total % vec || c.c_off + C > c.C_total) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d channels", k);
+        if (c.spatial == MRISR_SP_UP2 && (c.off_y + 2 * H > c.H || c.off_x + 2 * W > c.W)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d UP2 extent", k);
+        if (c.spatial == MRISR_SP_POOL2 && (c.H != H / 2 || c.W != W / 2)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d POOL2 extent", k);
+        p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode};
+    }
+    const int nvec = C / vec, ppb = 256 / nvec;
+    int ppblk = ppb * 16;
+    const int HW = H * W;
+    if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
+    p.pix_per_block = ppblk;
+    dim3 grid(ceil_div(HW, ppblk), N);
+    if (dtype == MRISR_BF16) act_bwd_reduce_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else if (dtype == MRISR_F32) act_bwd_reduce_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("act_bwd_reduce");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// red[N][C][2] -> dgamma[C] += sum_n B, dbeta[C] += sum_n A, and the pass-2 coefficients
+//   dx = g*cA + x*cB + cC  with  cA = rstd*gamma, cB = -rstd^2*S2/M, cC = mean*rstd^2*S2/M - rstd*S1/M
+//   S1[n,g] = sum_{c in g} gamma_c A[n,c],  S2[n,g] = sum_{c in g} gamma_c B[n,c],  M = count.
+__global__ void act_bwd_finalize_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
+                                        const float* __restrict__ meanrstd, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, float* __restrict__ coef, int N, int C,
+                                        int groups, float inv_count) {
+    // one block per (n, group); coef is [3][N][C]
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int gs = C / groups;
+    __shared__ float s1s, s2s;
+    if (threadIdx.x == 0) { s1s = 0.f; s2s = 0.f; }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = threadIdx.x; j < gs; j += blockDim.x) {
+        const int c = g * gs + j;
+        const float A = red[((size_t)n * C + c) * 2], B = red[((size_t)n * C + c) * 2 + 1];
+        s1 += gamma[c] * A;
+        s2 += gamma[c] * B;
+        atomic_add_f32(&dbeta[c], A);
+        atomic_add_f32(&dgamma[c], B);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s1s, s1); atomicAdd(&s2s, s2); }
+    __syncthreads();
+    const float mean = meanrstd[((size_t)n * groups + g) * 2], rstd = meanrstd[((size_t)n * groups + g) * 2 + 1];
+    const float S1 = s1s * inv_count, S2 = s2s * inv_count;
+    const size_t NC = (size_t)N * C;
+    for (int j = threadIdx.x; j < gs; j += blockDim.x) {
+        const int c = g * gs + j;
+        coef[(size_t)n * C + c] = rstd * gamma[c];
+        coef[NC + (size_t)n * C + c] = -rstd * rstd * S2;
+        coef[2 * NC + (size_t)n * C + c] = mean * rstd * rstd * S2 - rstd * S1;
+    }
+}
+
+extern "C" int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* meanrstd, float* dgamma,
+                                      float* dbeta, float* coef, int N, int C, int groups, double count,
+                                      void* stream) {
+    if (!red || !gamma || !meanrstd || !dgamma || !dbeta || !coef) MRISR_FAIL(MRISR_E_ARG, "act_bwd_finalize: null pointer");
+    if (groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_finalize: C %d groups %d", C, groups);
+    act_bwd_finalize_kernel<<<N * groups, 64, 0, (hipStream_t)stream>>>(red, gamma, meanrstd, dgamma, dbeta, coef, N, C,
+                                                                       groups, (float)(1.0 / count));
+    MRISR_CHECK_LAUNCH("act_bwd_finalize");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                            const float* __restrict__ coef, T* __restrict__ dx, int N,
+                                                            int H, int W, int C, int out_mode) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = C / VEC;
+    const size_t NC = (size_t)N * C;
+    const size_t total = (size_t)N * H * W * nvec;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        const size_t pix = idx / nvec;             // n*H*W + y*W + x
+        const int n = pix / ((size_t)H * W);
+        const int c = cv * VEC;
+        const Vec16<T> xv = load_vec16(x + pix * C + c), gv = load_vec16(g + pix * C + c);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const size_t k = (size_t)n * C + c + e;
+            o.set(e, gv.get(e) * coef[k] + xv.get(e) * coef[NC + k] + coef[2 * NC + k]);
+        }
+        if (out_mode == MRISR_OUT_PLAIN) {
+            store_vec16(dx + pix * C + c, o);
+        } else {   // inverse PixelShuffle(2): (n, Y, X, c') -> (n, Y/2, X/2, 4c' + 2(Y&1) + (X&1))
+            const int rem = pix - (size_t)n * H * W;
+            const int Y = rem / W, X = rem - Y * W;
+            T* dst = dx + (((size_t)n * (H / 2) + (Y >> 1)) * (W / 2) + (X >> 1)) * (4 * C) + 2 * (Y & 1) + (X & 1);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[4 * (c + e)] = from_f32<T>(o.get(e));
+        }
+    }
+}
+
+extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N, int H,
+                                   int W, int C, int out_mode, void* stream) {
+    if (!x || !g || !coef || !dx) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: C %d", C);
+    if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && ((H | W) & 1)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: odd dims with pixel shuffle");
+    const size_t total = (size_t)N * H * W * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == MRISR_BF16)
+        act_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C, out_mode);
+    else if (dtype == MRISR_F32)
+        act_bwd_apply_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)g, coef, (float*)dx, N, H, W, C, out_mode);
+    else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("act_bwd_apply");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dalpha += sigmoid'(alpha) * sum da * (act0 - act1)        (unet_model.py:206-207)
+template <typename T>
+__global__ __launch_bounds__(256) void blend_alpha_grad_kernel(const T* __restrict__ da, const T* __restrict__ x0,
+                                                               const float* __restrict__ sc0, const float* __restrict__ sh0,
+                                                               const T* __restrict__ x1, const float* __restrict__ sc1,
+                                                               const float* __restrict__ sh1, const float* __restrict__ alpha,
+                                                               float* __restrict__ dalpha, int N, int HW, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = C / VEC;
+    const size_t total = (size_t)N * HW * nvec;
+    float s = 0.f;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        const size_t pix = idx / nvec;
+        const int n = pix / HW, c = cv * VEC;
+        const Vec16<T> d = load_vec16(da + pix * C + c), a = load_vec16(x0 + pix * C + c), b = load_vec16(x1 + pix * C + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const size_t k = (size_t)n * C + c + e;
+            s += d.get(e) * (lrelu(a.get(e) * sc0[k] + sh0[k]) - lrelu(b.get(e) * sc1[k] + sh1[k]));
+        }
+    }
+    __shared__ float part[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sg = 1.f / (1.f + __expf(-alpha[0]));
+        atomic_add_f32(dalpha, (part[0] + part[1] + part[2] + part[3]) * sg * (1.f - sg));
+    }
+}
+
+extern "C" int mrisr_blend_alpha_grad(int dtype, const void* da, const void* x0, const float* scale0,
+                                      const float* shift0, const void* x1, const float* scale1, const float* shift1,
+                                      const float* alpha, float* dalpha, int N, int H, int W, int C, void* stream) {
+    if (!da || !x0 || !x1 || !scale0 || !shift0 || !scale1 || !shift1 || !alpha || !dalpha) MRISR_FAIL(MRISR_E_ARG, "blend_alpha_grad: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "blend_alpha_grad: C %d", C);
+    const size_t total = (size_t)N * H * W * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (dtype == MRISR_BF16)
+        blend_alpha_grad_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)da, (const bf16_t*)x0, scale0, shift0, (const bf16_t*)x1, scale1, shift1, alpha, dalpha, N, H * W, C);
+    else if (dtype == MRISR_F32)
+        blend_alpha_grad_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)da, (const float*)x0, scale0, shift0, (const float*)x1, scale1, shift1, alpha, dalpha, N, H * W, C);
+    else MRISR_FAIL(MRISR_E_DTYPE, "blend_alpha_grad: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("blend_alpha_grad");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[c] += sum over pixels of x[pixel][c]   (bias gradient of nn.Conv2d(bias=True), unet_model.py:101)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, size_t npix,
+                                                          int C, int pix_per_block) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float lds[256 * VEC];
+    const int t = threadIdx.x;
+    const int nvec = C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec;
+    const bool active = pl < ppb;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    const size_t end = min(npix, (size_t)(blockIdx.x + 1) * pix_per_block);
+    if (active)
+        for (size_t pix = (size_t)blockIdx.x * pix_per_block + pl; pix < end; pix += ppb) {
+            const Vec16<T> v = load_vec16(x + pix * C + cv * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += v.get(e);
+        }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) lds[t * VEC + e] = active ? s[e] : 0.f;
+    __syncthreads();
+    for (int i = t; i < nvec * VEC; i += 256) {
+        const int cvj = i / VEC, e = i - cvj * VEC;
+        float a = 0.f;
+        for (int q = 0; q < ppb; ++q) a += lds[(q * nvec + cvj) * VEC + e];
+        atomic_add_f32(&out[i], a);
+    }
+}
+
+extern "C" int mrisr_channel_sum(int dtype, const void* x, float* out, size_t npix, int C, void* stream) {
+    if (!x || !out) MRISR_FAIL(MRISR_E_ARG, "channel_sum: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec || C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "channel_sum: C %d", C);
+    const int ppb = 256 / (C / vec);
+    const int ppblk = ppb * 32;
+    const int blocks = (int)((npix + ppblk - 1) / ppblk);
+    if (dtype == MRISR_BF16) channel_sum_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, out, npix, C, ppblk);
+    else if (dtype == MRISR_F32) channel_sum_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, out, npix, C, ppblk);
+    else MRISR_FAIL(MRISR_E_DTYPE, "channel_sum: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("channel_sum");
+    return MRISR_OK;
+}

@@ -1,0 +1,350 @@
+"""Host-side schedule of the U-Net forward / backward over libmrisr kernels.
+
+This is the MI355X replacement for what autograd + aten do for
+``/root/reference/models/unet_model.py:189-211``: an explicit, hand-ordered list of kernel
+launches on the caller's HIP stream.  Activations are NHWC; only the RAW convolution outputs and
+their GroupNorm statistics are stored - GroupNorm-apply, LeakyReLU, max-pool, bilinear upsample,
+concat, pixel-shuffle and the alpha blend live inside the convolution loaders/epilogues.
+
+``Node``  = one raw conv output + its GroupNorm state.
+``Layer`` = one convolution (sources -> node).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+
+GN_GROUPS = 8
+GN_EPS = 1e-5
+
+
+def _dt(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return L.BF16
+    if dtype == torch.float32:
+        return L.F32
+    raise ValueError(f"unsupported compute dtype {dtype} (use torch.float32 or torch.bfloat16)")
+
+
+@dataclass
+class Node:
+    name: str
+    C: int                      # channels of the stored tensor
+    gamma: str                  # state_dict keys of the GroupNorm affine
+    beta: str
+    shuffled: bool = False      # stored pixel-shuffled (conv produced 4*C channels at half size)
+    # per-forward state
+    N: int = 0
+    H: int = 0
+    W: int = 0
+    raw: Optional[torch.Tensor] = None
+    stats: Optional[torch.Tensor] = None       # [N][8][2] double (view of the arena)
+    scale: Optional[torch.Tensor] = None       # [N][C]
+    shift: Optional[torch.Tensor] = None
+    meanrstd: Optional[torch.Tensor] = None    # [N][8][2]
+    consumers: list = field(default_factory=list)   # backward: (da, C_total, c_off, H, W, spatial, oy, ox, wmode)
+
+
+@dataclass
+class Source:
+    node: Node
+    spatial: int = L.SP_NONE
+
+
+@dataclass
+class Layer:
+    name: str                   # weight key without ".weight"
+    cin: int
+    cout: int
+    ks: int
+    srcs: List[Source]
+    out: Node
+    combine: int = L.COMBINE_CONCAT
+    bias: bool = False
+    out_mode: int = L.OUT_PLAIN
+    # per-forward geometry
+    H: int = 0
+    W: int = 0
+    offs: list = field(default_factory=list)
+
+
+class UNetEngine:
+    """Executes UNetSuperRes on one GPU.  ``params``: dict key -> fp32 tensor (conv weights in
+    channels_last storage, i.e. physically [Cout][kh][kw][Cin]); ``grads``: same keys."""
+
+    def __init__(self, base_filters: int, in_channels: int = 1, out_channels: int = 1):
+        if in_channels != 1 or out_channels != 1:
+            raise NotImplementedError("the HIP path implements the reference's 1->1 channel configuration "
+                                      "(scripts/train.py:167-173, scripts/infer.py:46-51)")
+        if base_filters % 16:
+            raise ValueError("base_filters must be a multiple of 16 (GroupNorm(8, base_filters // 2))")
+        f = self.f = base_filters
+        self.nodes: Dict[str, Node] = {}
+        self.layers: List[Layer] = []
+
+        def node(name, c, gn_prefix_w, gn_prefix_b, shuffled=False):
+            n = Node(name, c, gn_prefix_w, gn_prefix_b, shuffled)
+            self.nodes[name] = n
+            return n
+
+        def dconv(prefix, src: List[Source], cin, cout, combine=L.COMBINE_CONCAT):
+            a = node(f"{prefix}.double_conv.0", cout, f"{prefix}.double_conv.1.weight", f"{prefix}.double_conv.1.bias")
+            self.layers.append(Layer(f"{prefix}.double_conv.0", cin, cout, 3, src, a, combine))
+            b = node(f"{prefix}.double_conv.3", cout, f"{prefix}.double_conv.4.weight", f"{prefix}.double_conv.4.bias")
+            self.layers.append(Layer(f"{prefix}.double_conv.3", cout, cout, 3, [Source(a)], b))
+            return b
+
+        # encoder (unet_model.py:137-140); the stem conv (Cin = 1) has its own kernel
+        self.stem = node("inc.double_conv.0", f, "inc.double_conv.1.weight", "inc.double_conv.1.bias")
+        x1 = node("inc.double_conv.3", f, "inc.double_conv.4.weight", "inc.double_conv.4.bias")
+        self.layers.append(Layer("inc.double_conv.3", f, f, 3, [Source(self.stem)], x1))
+        x2 = dconv("down1.maxpool_conv.1", [Source(x1, L.SP_POOL2)], f, 2 * f)
+        x3 = dconv("down2.maxpool_conv.1", [Source(x2, L.SP_POOL2)], 2 * f, 4 * f)
+        x4 = dconv("down3.maxpool_conv.1", [Source(x3, L.SP_POOL2)], 4 * f, 8 * f)
+        # decoder (unet_model.py:144-146, 70-94)
+        u = x4
+        for j, (skip, cout) in enumerate(((x3, 4 * f), (x2, 2 * f), (x1, f)), start=1):
+            up = node(f"up{j}.up.1", cout, f"up{j}.up.2.weight", f"up{j}.up.2.bias")
+            self.layers.append(Layer(f"up{j}.up.1", 2 * cout, cout, 1, [Source(u, L.SP_UP2)], up))
+            u = dconv(f"up{j}.conv", [Source(skip), Source(up)], 2 * cout, cout)
+        # dual-branch head (unet_model.py:150-173)
+        fb = node("final_up_bilinear.1", f // 2, "final_up_bilinear.2.weight", "final_up_bilinear.2.bias")
+        self.layers.append(Layer("final_up_bilinear.1", f, f // 2, 3, [Source(u, L.SP_UP2)], fb))
+        ps = node("final_up_pixelshuffle.conv", f // 2, "final_up_pixelshuffle.norm.weight",
+                  "final_up_pixelshuffle.norm.bias", shuffled=True)
+        self.layers.append(Layer("final_up_pixelshuffle.conv", f, 2 * f, 3, [Source(u)], ps, bias=True,
+                                 out_mode=L.OUT_PIXEL_SHUFFLE2))
+        fc = node("final_conv.0", f // 2, "final_conv.1.weight", "final_conv.1.bias")
+        self.layers.append(Layer("final_conv.0", f // 2, f // 2, 3, [Source(fb), Source(ps)], fc,
+                                 combine=L.COMBINE_BLEND))
+        self.head_in = fc
+        self._packed: Dict[tuple, torch.Tensor] = {}
+        self._pack_versions: Dict[tuple, int] = {}
+
+    # ------------------------------------------------------------------ weights
+    def _packed_weight(self, layer: Layer, params, dt: int, flip: int, stream, force: bool = False):
+        w = params[layer.name + ".weight"]
+        key = (layer.name, dt, flip)
+        ver = (w.data_ptr(), w._version)
+        buf = self._packed.get(key)
+        if buf is None or buf.device != w.device:
+            nbytes = L.load().mrisr_packed_weight_bytes(dt, layer.cin if flip else layer.cout,
+                                                        layer.cout if flip else layer.cin, layer.ks)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            self._packed[key] = buf
+            self._pack_versions.pop(key, None)
+        if force or self._pack_versions.get(key) != ver:
+            L.call("mrisr_pack_weights", dt, w.data_ptr(), layer.cout, layer.cin, layer.ks, flip, buf.data_ptr(), stream)
+            self._pack_versions[key] = ver
+        return buf
+
+    # ------------------------------------------------------------------ descriptors
+    def _desc(self, layer: Layer, dt: int, N: int, params) -> L.ConvDesc:
+        d = L.ConvDesc()
+        d.dtype, d.N, d.H, d.W = dt, N, layer.H, layer.W
+        d.Cin, d.Cout, d.ksize, d.nsrc = layer.cin, layer.cout, layer.ks, len(layer.srcs)
+        d.combine, d.out_mode, d.groups, d.relu_out = layer.combine, layer.out_mode, GN_GROUPS, 0
+        for i, (s, (oy, ox)) in enumerate(zip(layer.srcs, layer.offs)):
+            n = s.node
+            d.src[i].ptr = n.raw.data_ptr()
+            d.src[i].scale = n.scale.data_ptr()
+            d.src[i].shift = n.shift.data_ptr()
+            d.src[i].C, d.src[i].H, d.src[i].W = n.C, n.H, n.W
+            d.src[i].mode, d.src[i].spatial = L.SRC_NORM, s.spatial
+            d.src[i].off_y, d.src[i].off_x = oy, ox
+        if layer.combine == L.COMBINE_BLEND:
+            d.blend_alpha = params["alpha"].data_ptr()
+        return d
+
+    @staticmethod
+    def _virtual_hw(s: Source):
+        n = s.node
+        if s.spatial == L.SP_POOL2:
+            return n.H // 2, n.W // 2
+        if s.spatial == L.SP_UP2:
+            return 2 * n.H, 2 * n.W
+        return n.H, n.W
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, params, x: torch.Tensor, dtype: torch.dtype, training: bool):
+        """x: (N,1,H,W) fp32 contiguous on the GPU.  Returns (out (N,1,2H,2W) fp32, ctx)."""
+        dt = _dt(dtype)
+        dev = x.device
+        N, _, H, W = x.shape
+        if H < 8 or W < 8:
+            raise ValueError("input must be at least 8x8 (three 2x2 max-pools)")
+        st = L.stream_ptr()
+        f = self.f
+        nodes = list(self.nodes.values())
+        arena = torch.zeros(len(nodes) * N * GN_GROUPS * 2, dtype=torch.float64, device=dev)
+        for i, n in enumerate(nodes):
+            n.stats = arena[i * N * GN_GROUPS * 2:(i + 1) * N * GN_GROUPS * 2]
+            n.consumers = []
+
+        def finalize(n: Node):
+            n.scale = torch.empty(N * n.C, dtype=torch.float32, device=dev)
+            n.shift = torch.empty(N * n.C, dtype=torch.float32, device=dev)
+            n.meanrstd = torch.empty(N * GN_GROUPS * 2, dtype=torch.float32, device=dev)
+            count = float((n.C // GN_GROUPS) * n.H * n.W)
+            L.call("mrisr_gn_finalize", n.stats.data_ptr(), params[n.gamma].data_ptr(), params[n.beta].data_ptr(),
+                   n.scale.data_ptr(), n.shift.data_ptr(), n.meanrstd.data_ptr(), N, n.C, GN_GROUPS, count,
+                   GN_EPS, st)
+
+        # stem
+        s = self.stem
+        s.N, s.H, s.W = N, H, W
+        s.raw = torch.empty((N, H, W, f), dtype=dtype, device=dev)
+        L.call("mrisr_stem_forward", dt, x.data_ptr(), params["inc.double_conv.0.weight"].data_ptr(),
+               s.raw.data_ptr(), s.stats.data_ptr(), N, H, W, f, GN_GROUPS, st)
+        finalize(s)
+
+        for layer in self.layers:
+            # conv geometry: first source fixes the size (skip for concat); others are padded into it
+            vh, vw = self._virtual_hw(layer.srcs[0])
+            layer.H, layer.W = vh, vw
+            layer.offs = []
+            for sidx, src in enumerate(layer.srcs):
+                h, w = self._virtual_hw(src)
+                dy, dx = vh - h, vw - w
+                if dy < 0 or dx < 0:
+                    raise RuntimeError(f"{layer.name}: source larger than the conv input")
+                layer.offs.append((dy // 2, dx // 2))        # F.pad split, unet_model.py:89-90
+            o = layer.out
+            o.N = N
+            if layer.out_mode == L.OUT_PIXEL_SHUFFLE2:
+                o.H, o.W = 2 * vh, 2 * vw
+            else:
+                o.H, o.W = vh, vw
+            o.raw = torch.empty((N, o.H, o.W, o.C), dtype=dtype, device=dev)
+            d = self._desc(layer, dt, N, params)
+            # training: the optimiser rewrites the masters through raw pointers every step -> always repack
+            d.wpacked = self._packed_weight(layer, params, dt, 0, st, force=training).data_ptr()
+            d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
+            d.out = o.raw.data_ptr()
+            d.stats = o.stats.data_ptr()
+            L.call("mrisr_conv_forward", C.byref(d), st)
+            finalize(o)
+
+        hn = self.head_in
+        out = torch.empty((N, 1, hn.H, hn.W), dtype=torch.float32, device=dev)
+        L.call("mrisr_head_forward", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
+               params["final_conv.3.weight"].data_ptr(), params["final_conv.3.bias"].data_ptr(), out.data_ptr(),
+               N, hn.H, hn.W, hn.C, st)
+        ctx = None
+        if training:
+            ctx = {"x": x, "out": out, "dtype": dtype, "N": N, "arena": arena,
+                   "nodes": {k: (n.N, n.H, n.W, n.raw, n.scale, n.shift, n.meanrstd) for k, n in self.nodes.items()},
+                   "layers": {l.name: (l.H, l.W, list(l.offs)) for l in self.layers}}
+        else:
+            for n in nodes:
+                n.raw = n.scale = n.shift = n.meanrstd = n.stats = None
+        return out, ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, params, grads, ctx, dout: torch.Tensor, bucket_hook=None):
+        """Accumulates parameter gradients into ``grads`` (fp32, same layout as params).
+        ``bucket_hook(layer_name)`` is called after the gradients of a layer are complete
+        (reverse execution order) so that a data-parallel driver can start its all-reduce."""
+        dtype = ctx["dtype"]
+        dt = _dt(dtype)
+        N = ctx["N"]
+        x = ctx["x"]
+        dev = x.device
+        st = L.stream_ptr()
+        for k, n in self.nodes.items():
+            n.N, n.H, n.W, n.raw, n.scale, n.shift, n.meanrstd = ctx["nodes"][k]
+            n.consumers = []
+        for l in self.layers:
+            l.H, l.W, l.offs = ctx["layers"][l.name]
+        dout = dout.contiguous()
+
+        def node_backward(n: Node) -> torch.Tensor:
+            """dL/dact (gathered from consumers) -> dL/d(raw conv output), plus GN affine grads."""
+            cons = (L.Consumer * 2)()
+            uses_alpha = False
+            for i, (da, ctot, coff, ch, cw, sp, oy, ox, wm) in enumerate(n.consumers):
+                cons[i].da = da.data_ptr()
+                cons[i].C_total, cons[i].c_off, cons[i].H, cons[i].W = ctot, coff, ch, cw
+                cons[i].spatial, cons[i].off_y, cons[i].off_x, cons[i].weight_mode = sp, oy, ox, wm
+                uses_alpha |= wm != 0
+            g = torch.empty_like(n.raw)
+            red = torch.zeros(N * n.C * 2, dtype=torch.float32, device=dev)
+            L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                   n.meanrstd.data_ptr(), len(n.consumers), cons,
+                   params["alpha"].data_ptr() if uses_alpha else None, g.data_ptr(), red.data_ptr(),
+                   N, n.H, n.W, n.C, GN_GROUPS, st)
+            coef = torch.empty(3 * N * n.C, dtype=torch.float32, device=dev)
+            count = float((n.C // GN_GROUPS) * n.H * n.W)
+            L.call("mrisr_act_bwd_finalize", red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
+                   grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), coef.data_ptr(), N, n.C, GN_GROUPS, count, st)
+            if n.shuffled:
+                dx = torch.empty((N, n.H // 2, n.W // 2, 4 * n.C), dtype=dtype, device=dev)
+                mode = L.OUT_PIXEL_SHUFFLE2
+            else:
+                dx = torch.empty_like(n.raw)
+                mode = L.OUT_PLAIN
+            L.call("mrisr_act_bwd_apply", dt, n.raw.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(),
+                   N, n.H, n.W, n.C, mode, st)
+            n.consumers = []
+            return dx
+
+        # head (unet_model.py:172, 211)
+        hn = self.head_in
+        da = torch.empty_like(hn.raw)
+        L.call("mrisr_head_backward", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
+               params["final_conv.3.weight"].data_ptr(), ctx["out"].data_ptr(), dout.data_ptr(), da.data_ptr(),
+               grads["final_conv.3.weight"].data_ptr(), grads["final_conv.3.bias"].data_ptr(),
+               N, hn.H, hn.W, hn.C, st)
+        hn.consumers.append((da, hn.C, 0, hn.H, hn.W, L.SP_NONE, 0, 0, 0))
+        if bucket_hook:
+            bucket_hook("final_conv.3")
+
+        for layer in reversed(self.layers):
+            o = layer.out
+            dy = node_backward(o)
+            d = self._desc(layer, dt, N, params)
+            L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(), grads[layer.name + ".weight"].data_ptr(), st)
+            if layer.bias:
+                L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
+                       N * layer.H * layer.W, layer.cout, st)
+            # input gradient: the same implicit-GEMM kernel on dy with mirrored, transposed weights
+            dd = L.ConvDesc()
+            dd.dtype, dd.N, dd.H, dd.W = dt, N, layer.H, layer.W
+            dd.Cin, dd.Cout, dd.ksize, dd.nsrc = layer.cout, layer.cin, layer.ks, 1
+            dd.combine, dd.out_mode, dd.groups, dd.relu_out = L.COMBINE_CONCAT, L.OUT_PLAIN, 0, 0
+            dd.src[0].ptr = dy.data_ptr()
+            dd.src[0].C, dd.src[0].H, dd.src[0].W = layer.cout, layer.H, layer.W
+            dd.src[0].mode, dd.src[0].spatial = L.SRC_RAW, L.SP_NONE
+            dd.wpacked = self._packed_weight(layer, params, dt, 1, st, force=True).data_ptr()
+            dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
+            dd.out = dain.data_ptr()
+            L.call("mrisr_conv_forward", C.byref(dd), st)
+            if layer.combine == L.COMBINE_BLEND:
+                a, b = layer.srcs[0].node, layer.srcs[1].node
+                L.call("mrisr_blend_alpha_grad", dt, dain.data_ptr(), a.raw.data_ptr(), a.scale.data_ptr(),
+                       a.shift.data_ptr(), b.raw.data_ptr(), b.scale.data_ptr(), b.shift.data_ptr(),
+                       params["alpha"].data_ptr(), grads["alpha"].data_ptr(), N, layer.H, layer.W, layer.cin, st)
+                a.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 1))
+                b.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 2))
+            else:
+                coff = 0
+                for src, (oy, ox) in zip(layer.srcs, layer.offs):
+                    src.node.consumers.append((dain, layer.cin, coff, layer.H, layer.W, src.spatial, oy, ox, 0))
+                    coff += src.node.C
+            if bucket_hook:
+                bucket_hook(layer.name)
+
+        # stem (no input gradient: the image needs none)
+        dy = node_backward(self.stem)
+        L.call("mrisr_stem_wgrad", dt, x.data_ptr(), dy.data_ptr(), grads["inc.double_conv.0.weight"].data_ptr(),
+               N, self.stem.H, self.stem.W, self.f, st)
+        if bucket_hook:
+            bucket_hook("inc.double_conv.0")
+        for n in self.nodes.values():
+            n.raw = n.scale = n.shift = n.meanrstd = n.stats = None
+            n.consumers = []

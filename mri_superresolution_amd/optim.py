@@ -1,0 +1,89 @@
+"""Fused Adam over the model's flat fp32 buffers (one HIP kernel per step).
+
+Drop-in for ``optim.Adam(model.parameters(), lr, weight_decay)`` as used by
+``/root/reference/scripts/train.py:186`` (L2 weight decay added to the gradient, eps 1e-8, betas
+(0.9, 0.999), bias correction), and usable with ``optim.lr_scheduler.ReduceLROnPlateau``
+(train.py:189-191) because it is a ``torch.optim.Optimizer`` with one param group.
+``state_dict()`` is emitted in torch.optim.Adam's layout (per-parameter ``step`` / ``exp_avg`` /
+``exp_avg_sq``) so checkpoints stay interchangeable (train.py:410-418).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if not hasattr(model, "flat_params"):
+            raise TypeError("FusedAdam needs a model with flat parameter storage (UNetSuperRes)")
+        self.model = model
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step = 0
+        self.grad_scale = 1.0           # 1/world_size when gradients were sum-all-reduced
+        self._alloc()
+
+    def _alloc(self):
+        flat = self.model.flat_params
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self._flat_ptr = flat.data_ptr()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        m = self.model
+        if m.flat_params.data_ptr() != self._flat_ptr:
+            raise RuntimeError("model storage was re-created (model.to(...) after the optimizer was built)")
+        if not m.flat_params.is_cuda:
+            raise RuntimeError("FusedAdam runs on the GPU only (no CPU fallback)")
+        for name, p in m.named_parameters():
+            if p.grad is not None and p.grad.data_ptr() != m._grad_views[name].data_ptr():
+                m._grad_views[name].copy_(p.grad)          # foreign gradient tensor: stage it
+        g = self.param_groups[0]
+        self._step += 1
+        L.call("mrisr_adam_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
+               self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
+               float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, float(self.grad_scale),
+               L.stream_ptr())
+        return loss
+
+    # ---- torch.optim.Adam-compatible checkpoint format
+    def _views(self, flat):
+        out = []
+        for name, p in self.model.named_parameters():
+            off, n = self.model._offsets[name]
+            v = flat[off:off + n]
+            if p.dim() == 4:
+                co, ci, kh, kw = p.shape
+                v = v.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                v = v.view(p.shape)
+            out.append(v)
+        return out
+
+    def state_dict(self):
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        n = len(self.param_groups[0]["params"])
+        groups[0]["params"] = list(range(n))
+        state = {}
+        if self._step > 0:
+            for i, (ea, es) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq))):
+                state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": ea.clone(), "exp_avg_sq": es.clone()}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            for k, v in src.items():
+                if k != "params":
+                    g[k] = v
+        st = sd.get("state", {})
+        if st:
+            for i, (ea, es) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq))):
+                ent = st.get(i, st.get(str(i)))
+                if ent is None:
+                    continue
+                ea.copy_(ent["exp_avg"])
+                es.copy_(ent["exp_avg_sq"])
+                self._step = int(float(ent["step"]))

@@ -1,0 +1,175 @@
+"""MI355X-native mirror of ``/root/reference/utils/losses.py`` (same public names and signatures).
+
+L1 + Gaussian-window SSIM run as ONE fused HIP pass over (output, target) with an analytic
+backward (``csrc/loss.hip``); there is no CPU path.  Differences from the reference, by design:
+ * no per-call ``.item()`` host syncs (losses.py:208,225,226,236): the components of the last call
+   stay on the device in ``CombinedLoss.last_components`` = [total, l1, ssim, ...per-sample ssim];
+ * gradients flow to the first argument only (the network output), which is all train.py needs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+# VGG normalisation constants (reference losses.py:7-8)
+VGG_MEAN = [0.485, 0.456, 0.406]
+VGG_STD = [0.229, 0.224, 0.225]
+
+_WINDOW = 11    # the fused kernel is specialised for the 11-tap window every caller uses
+
+
+def gaussian_window(window_size: int, sigma: float):
+    """1-D Gaussian window, normalised to sum 1 (reference losses.py:10-18)."""
+    coords = torch.arange(window_size, dtype=torch.float32) - window_size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def create_window(window_size: int, channel: int, sigma: float, device: torch.device):
+    """2-D window (C,1,ws,ws) = outer product of the 1-D window (reference losses.py:20-25)."""
+    w1 = gaussian_window(window_size, sigma).to(device).unsqueeze(1)
+    return w1.mm(w1.t()).expand(channel, 1, window_size, window_size).contiguous()
+
+
+def _planes(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("ssim / CombinedLoss run on an MI355X through libmrisr.so only; got a CPU tensor "
+                           "(there is no CPU fallback)")
+    if t.dim() != 4:
+        raise ValueError(f"expected (N,C,H,W), got {tuple(t.shape)}")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _SSIML1(torch.autograd.Function):
+    """kind 0: returns l1_w*L1 + ssim_w*(1-clamp(SSIM,0,1));  kind 1: returns mean SSIM."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, l1_w, ssim_w, sigma, val_range, kind, holder):
+        a, b = _planes(img1), _planes(img2)
+        if a.shape != b.shape:
+            raise ValueError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        n, c, h, w = a.shape
+        planes = n * c
+        need_grad = ctx.needs_input_grad[0]
+        st = L.stream_ptr()
+        sums = torch.zeros(planes * 2, dtype=torch.float64, device=a.device)
+        coef = torch.empty(3 * planes * h * w, dtype=torch.float32, device=a.device) if (need_grad and ssim_w != 0) else None
+        L.call("mrisr_ssim_l1_forward", a.data_ptr(), b.data_ptr(), sums.data_ptr(), L.ptr(coef), planes, h, w,
+               float(val_range), float(sigma), st)
+        comp = torch.empty(3 + planes, dtype=torch.float32, device=a.device)
+        L.call("mrisr_loss_finalize", sums.data_ptr(), planes, h, w, float(l1_w), float(ssim_w), comp.data_ptr(), st)
+        if holder is not None:
+            holder.last_components = comp
+        ctx.save_for_backward(a, b, coef, sums)
+        ctx.cfg = (float(l1_w), float(ssim_w), float(sigma), kind, planes, h, w)
+        return comp[0].clone() if kind == 0 else comp[2].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b, coef, sums = ctx.saved_tensors
+        l1_w, ssim_w, sigma, kind, planes, h, w = ctx.cfg
+        g = gout.detach().to(torch.float32).reshape(1).contiguous()
+        da = torch.empty_like(a)
+        if kind == 0:
+            L.call("mrisr_ssim_l1_backward", a.data_ptr(), b.data_ptr(), L.ptr(coef), sums.data_ptr(), g.data_ptr(),
+                   l1_w, ssim_w, da.data_ptr(), planes, h, w, sigma, L.stream_ptr())
+        else:   # d(mean ssim): weights (0, -1), no clamp
+            L.call("mrisr_ssim_l1_backward", a.data_ptr(), b.data_ptr(), L.ptr(coef), None, g.data_ptr(),
+                   0.0, -1.0, da.data_ptr(), planes, h, w, sigma, L.stream_ptr())
+        return da, None, None, None, None, None, None, None
+
+
+def ssim(img1, img2, window_size=11, sigma=1.5, val_range=1.0, device=None, window=None, size_average=True):
+    """SSIM between img1 and img2, computed in fp32 with zero padding (reference losses.py:27-81).
+    ``device`` / ``window`` are accepted for signature compatibility; the window is rebuilt from
+    (window_size, sigma) inside the kernel."""
+    if window_size != _WINDOW:
+        raise NotImplementedError(f"the fused SSIM kernel supports window_size={_WINDOW} only")
+    if img2.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("gradient w.r.t. the second ssim() argument is not implemented")
+    holder = type("H", (), {})()
+    val = _SSIML1.apply(img1, img2, 0.0, 1.0, sigma, val_range, 1, holder)
+    if size_average:
+        result = val
+    else:
+        n, c = img1.shape[0], img1.shape[1]
+        result = holder.last_components[3:].view(n, c).mean(1)
+    if img1.dtype != torch.float32 and img1.dtype == img2.dtype:
+        result = result.to(img1.dtype)
+    return result
+
+
+class VGGFeatureExtractor(nn.Module):
+    """Reference losses.py:83-118 builds torchvision's pretrained VGG19 here.  torchvision and its
+    ImageNet weights are not available offline in this build; the HIP conv kernels
+    can run the VGG19 feature stack, but it is not wired up in this round."""
+
+    def __init__(self, feature_layer_idx=35, use_maxpool=False):
+        super().__init__()
+        raise NotImplementedError(
+            "VGG19 perceptual features are not available in this build: torchvision / ImageNet weights "
+            "are absent offline (perceptual_weight must be 0)")
+
+
+class PerceptualLoss(nn.Module):
+    """Reference losses.py:120-151."""
+
+    def __init__(self, feature_layer_idx=35, loss_type="l1"):
+        super().__init__()
+        if loss_type not in ("l1", "l2", "mse"):
+            raise ValueError(f"Unsupported loss type for PerceptualLoss: {loss_type}")
+        self.feature_extractor = VGGFeatureExtractor(feature_layer_idx=feature_layer_idx)
+
+
+class CombinedLoss(nn.Module):
+    """(1-s-p) * L1 + s * (1 - clamp(SSIM,0,1)) + p * Perceptual   (reference losses.py:153-240)."""
+
+    def __init__(self, ssim_weight=0.5, perceptual_weight=0.0, vgg_layer_idx=35, perceptual_loss_type="l1",
+                 window_size=11, sigma=1.5, val_range=1.0, device=torch.device("cpu")):
+        super().__init__()
+        if not (0 <= ssim_weight <= 1):
+            raise ValueError("ssim_weight must be between 0 and 1")
+        if not (0 <= perceptual_weight <= 1):
+            raise ValueError("perceptual_weight must be between 0 and 1")
+        if ssim_weight + perceptual_weight > 1:
+            raise ValueError("Sum of ssim_weight and perceptual_weight cannot exceed 1")
+        if window_size != _WINDOW:
+            raise NotImplementedError(f"the fused SSIM kernel supports window_size={_WINDOW} only")
+        self.ssim_weight = ssim_weight
+        self.perceptual_weight = perceptual_weight
+        self.l1_weight = 1.0 - ssim_weight - perceptual_weight
+        self.window_size = window_size
+        self.sigma = sigma
+        self.val_range = val_range
+        self.device = device
+        self.register_buffer("window", create_window(window_size, 1, sigma, torch.device("cpu")))
+        self.use_perceptual = perceptual_weight > 0
+        self.perceptual_loss = (PerceptualLoss(feature_layer_idx=vgg_layer_idx, loss_type=perceptual_loss_type)
+                                if self.use_perceptual else None)
+        self.last_components = None
+
+    def forward(self, output, target):
+        l1_w = self.l1_weight if self.l1_weight > 0 else 0.0
+        s_w = self.ssim_weight if self.ssim_weight > 0 else 0.0
+        if l1_w == 0.0 and s_w == 0.0 and not self.use_perceptual:
+            return 0.0                         # the reference returns the python float 0.0 here
+        return _SSIML1.apply(output, target, l1_w, s_w, self.sigma, self.val_range, 0, self)
+
+
+class SSIM(nn.Module):
+    """SSIM metric module (reference losses.py:242-266)."""
+
+    def __init__(self, window_size=11, sigma=1.5, val_range=1.0, device=None):
+        super().__init__()
+        if window_size != _WINDOW:
+            raise NotImplementedError(f"the fused SSIM kernel supports window_size={_WINDOW} only")
+        self.window_size = window_size
+        self.sigma = sigma
+        self.val_range = val_range
+        self.device = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.register_buffer("window", create_window(window_size, 1, sigma, torch.device("cpu")))
+
+    def forward(self, img1, img2):
+        return ssim(img1, img2, self.window_size, self.sigma, self.val_range, img1.device, None)

@@ -1,0 +1,310 @@
+"""Per-kernel parity tests (GPU): every libmrisr entry point called through the C-ABI and compared
+with the torch-CPU fp32 restatement of the same reference op.
+
+Tolerances: fp32 path (exact-fp32 MFMA) 2e-5 of the tensor's max (summation order only);
+bf16 path: operands are rounded to bf16 on BOTH sides, so the remaining error is the bf16 rounding
+of the stored result (2^-8 relative) -> 1e-2 of max for stored tensors, 2e-3 for fp32 outputs.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mri_superresolution_amd import _lib as L          # noqa: E402
+import hiputil as U                                    # noqa: E402
+
+DTS = [L.F32, L.BF16]
+TOL_OUT = {L.F32: 2e-5, L.BF16: 1e-2}      # stored in compute dtype
+TOL_F32 = {L.F32: 2e-5, L.BF16: 2e-3}      # fp32 results computed from rounded operands
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def gn_affine(n, c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return 0.5 + torch.rand(n, c, generator=g), 0.3 * torch.randn(n, c, generator=g)
+
+
+# ------------------------------------------------------------------------------------------- conv fwd
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 16, 32, 24, 40), (1, 64, 64, 33, 70), (1, 8, 16, 9, 13), (2, 96, 40, 16, 16)])
+def test_conv3x3_raw(dt, shape):
+    n, cin, cout, h, w = shape
+    x, wt = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.1)
+    out, stats = U.conv_forward(dt, [U.SrcSpec(x)], wt, h, w, 3)
+    ref = F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), padding=1)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    # GroupNorm statistics of the stored tensor
+    gs = cout // 8
+    o = out.view(n, 8, gs, h, w).double()
+    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-3 * o.abs().max().item())
+    assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv1x1_and_bias(dt):
+    n, cin, cout, h, w = 2, 64, 32, 20, 36
+    x, wt, b = rnd(n, cin, h, w, seed=3), rnd(cout, cin, 1, 1, seed=4, scale=0.2), rnd(cout, seed=5)
+    out, _ = U.conv_forward(dt, [U.SrcSpec(x)], wt, h, w, 1, bias=b)
+    ref = F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), b)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("spatial", [L.SP_NONE, L.SP_POOL2, L.SP_UP2])
+@pytest.mark.parametrize("ks", [3, 1])
+def test_conv_fused_norm_sources(dt, spatial, ks):
+    if ks == 1 and spatial == L.SP_POOL2:
+        pytest.skip("not used by the network")
+    n, cin, cout = 2, 32, 64
+    hs, ws = (22, 38) if spatial != L.SP_UP2 else (11, 19)
+    x = rnd(n, cin, hs, ws, seed=6)
+    sc, sh = gn_affine(n, cin, 7)
+    wt = rnd(cout, cin, ks, ks, seed=8, scale=0.1)
+    src = U.SrcSpec(x, L.SRC_NORM, spatial, sc, sh)
+    h, w = {L.SP_NONE: (hs, ws), L.SP_POOL2: (hs // 2, ws // 2), L.SP_UP2: (2 * hs, 2 * ws)}[spatial]
+    out, _ = U.conv_forward(dt, [src], wt, h, w, ks)
+    ref = F.conv2d(U.ref_conv_input([src], dt, h, w), U.rounded(wt, dt), padding=ks // 2)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_concat_with_pad_and_blend(dt):
+    n, c0, c1, cout, h, w = 1, 32, 16, 32, 25, 35          # odd skip size: the up path is padded (unet_model.py:86-90)
+    skip, up = rnd(n, c0, h, w, seed=9), rnd(n, c1, 24, 34, seed=10)
+    s0, s1 = gn_affine(n, c0, 11), gn_affine(n, c1, 12)
+    wt = rnd(cout, c0 + c1, 3, 3, seed=13, scale=0.1)
+    srcs = [U.SrcSpec(skip, L.SRC_NORM, L.SP_NONE, *s0), U.SrcSpec(up, L.SRC_NORM, L.SP_NONE, *s1, off=(0, 0))]
+    out, _ = U.conv_forward(dt, srcs, wt, h, w, 3)
+    ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w), U.rounded(wt, dt), padding=1)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    # blend of two normalised sources
+    a, b = rnd(n, 16, h, w, seed=14), rnd(n, 16, h, w, seed=15)
+    alpha = torch.tensor(0.3)
+    srcs = [U.SrcSpec(a, L.SRC_NORM, L.SP_NONE, *gn_affine(n, 16, 16)), U.SrcSpec(b, L.SRC_NORM, L.SP_NONE, *gn_affine(n, 16, 17))]
+    wt = rnd(16, 16, 3, 3, seed=18, scale=0.1)
+    out, _ = U.conv_forward(dt, srcs, wt, h, w, 3, combine=L.COMBINE_BLEND, alpha=alpha)
+    ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w, L.COMBINE_BLEND, alpha), U.rounded(wt, dt), padding=1)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_pixel_shuffle_epilogue(dt):
+    n, cin, cout, h, w = 2, 16, 32, 12, 20
+    x, wt, b = rnd(n, cin, h, w, seed=19), rnd(cout, cin, 3, 3, seed=20, scale=0.1), rnd(cout, seed=21)
+    out, stats = U.conv_forward(dt, [U.SrcSpec(x)], wt, h, w, 3, bias=b, out_mode=L.OUT_PIXEL_SHUFFLE2)
+    ref = F.pixel_shuffle(F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), b, padding=1), 2)
+    assert out.shape == ref.shape == (n, cout // 4, 2 * h, 2 * w)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    o = out.view(n, 8, cout // 32, 2 * h, 2 * w).double()
+    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-3 * o.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("ks", [3, 1])
+def test_conv_dgrad_via_flipped_weights(dt, ks):
+    n, cin, cout, h, w = 2, 32, 64, 19, 27
+    dy, wt = rnd(n, cout, h, w, seed=22), rnd(cout, cin, ks, ks, seed=23, scale=0.1)
+    keep = []
+    d = U.make_desc(dt, [U.SrcSpec(dy)], h, w, cout, cin, ks, keep=keep)
+    wp = U.pack(wt, dt, flip=1)
+    d.wpacked = wp.data_ptr()
+    out = torch.empty((n, h, w, cin), dtype=U.tdt(dt), device=U.DEV)
+    d.out = out.data_ptr()
+    L.call("mrisr_conv_forward", C.byref(d), U.stream())
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(U.rounded(dy, dt), U.rounded(wt, dt), padding=ks // 2)
+    assert U.relerr(U.nchw(out), ref) <= TOL_OUT[dt]
+
+
+# ------------------------------------------------------------------------------------------- wgrad
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", ["raw", "pool", "up", "concat", "k1"])
+def test_conv_wgrad(dt, case):
+    n = 2
+    if case == "raw":
+        cin, cout, h, w, ks = 64, 96, 21, 37, 3
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=30), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 31))]
+    elif case == "pool":
+        cin, cout, h, w, ks = 32, 64, 12, 17, 3
+        srcs = [U.SrcSpec(rnd(n, cin, 24, 35, seed=32), L.SRC_NORM, L.SP_POOL2, *gn_affine(n, cin, 33))]
+    elif case == "up":
+        cin, cout, h, w, ks = 32, 16, 24, 34, 3
+        srcs = [U.SrcSpec(rnd(n, cin, 12, 17, seed=34), L.SRC_NORM, L.SP_UP2, *gn_affine(n, cin, 35))]
+    elif case == "concat":
+        cin, cout, h, w, ks = 48, 32, 17, 33, 3
+        srcs = [U.SrcSpec(rnd(n, 32, h, w, seed=36), L.SRC_NORM, L.SP_NONE, *gn_affine(n, 32, 37)),
+                U.SrcSpec(rnd(n, 16, 16, 32, seed=38), L.SRC_NORM, L.SP_NONE, *gn_affine(n, 16, 39), off=(0, 0))]
+    else:
+        cin, cout, h, w, ks = 64, 32, 20, 28, 1
+        srcs = [U.SrcSpec(rnd(n, cin, 10, 14, seed=40), L.SRC_NORM, L.SP_UP2, *gn_affine(n, cin, 41))]
+    dy = rnd(n, cout, h, w, seed=42)
+    dw = U.conv_wgrad(dt, srcs, dy, cout, cin, h, w, ks)
+    xin = U.ref_conv_input(srcs, dt, h, w).requires_grad_(False)
+    wt = torch.zeros(cout, cin, ks, ks, requires_grad=True)
+    F.conv2d(xin, wt, padding=ks // 2).backward(U.rounded(dy, dt))
+    assert U.relerr(dw, wt.grad) <= TOL_F32[dt]
+
+
+# ------------------------------------------------------------------------------------------- stem / head
+@pytest.mark.parametrize("dt", DTS)
+def test_stem_forward_and_wgrad(dt):
+    n, cout, h, w = 2, 32, 19, 45
+    x, wt = torch.rand(n, 1, h, w, generator=torch.Generator().manual_seed(50)), rnd(cout, 1, 3, 3, seed=51)
+    xd, wd = x.to(U.DEV).contiguous(), wt.reshape(cout, 9).contiguous().to(U.DEV)
+    out = torch.empty((n, h, w, cout), dtype=U.tdt(dt), device=U.DEV)
+    stats = torch.zeros(n * 16, dtype=torch.float64, device=U.DEV)
+    L.call("mrisr_stem_forward", dt, xd.data_ptr(), wd.data_ptr(), out.data_ptr(), stats.data_ptr(), n, h, w, cout, 8, U.stream())
+    ref = F.conv2d(x, wt, padding=1)
+    assert U.relerr(U.nchw(out), ref) <= TOL_OUT[dt]
+    o = U.nchw(out).view(n, 8, cout // 8, h, w).double()
+    assert torch.allclose(stats.cpu().view(n, 8, 2)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    dy = rnd(n, cout, h, w, seed=52)
+    dw = torch.zeros(cout * 9, dtype=torch.float32, device=U.DEV)
+    L.call("mrisr_stem_wgrad", dt, xd.data_ptr(), U.nhwc(dy, dt).data_ptr(), dw.data_ptr(), n, h, w, cout, U.stream())
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(x, wr, padding=1).backward(U.rounded(dy, dt))
+    assert U.relerr(dw.cpu().view(cout, 1, 3, 3), wr.grad) <= TOL_F32[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_head_forward_backward(dt):
+    n, c, h, w = 2, 16, 23, 41
+    x = rnd(n, c, h, w, seed=60)
+    sc, sh = gn_affine(n, c, 61)
+    wt, b = rnd(c, seed=62, scale=0.3), torch.tensor([0.1])
+    xd, scd, shd, wd, bd = U.nhwc(x, dt), sc.to(U.DEV), sh.to(U.DEV), wt.to(U.DEV), b.to(U.DEV)
+    out = torch.empty((n, h, w), dtype=torch.float32, device=U.DEV)
+    L.call("mrisr_head_forward", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), n, h, w, c, U.stream())
+    act = F.leaky_relu(U.rounded(x, dt) * sc.view(n, c, 1, 1) + sh.view(n, c, 1, 1), 0.2).requires_grad_(True)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.sigmoid((act * wr.view(1, c, 1, 1)).sum(1) + br)
+    assert U.relerr(out.cpu(), ref.detach()) <= 1e-5
+    dout = rnd(n, h, w, seed=63)
+    ref.backward(dout)
+    da = torch.empty((n, h, w, c), dtype=U.tdt(dt), device=U.DEV)
+    dw, db = torch.zeros(c, device=U.DEV), torch.zeros(1, device=U.DEV)
+    L.call("mrisr_head_backward", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wd.data_ptr(), out.data_ptr(),
+           dout.to(U.DEV).data_ptr(), da.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, w, c, U.stream())
+    assert U.relerr(U.nchw(da), act.grad) <= TOL_OUT[dt]
+    assert U.relerr(dw.cpu(), wr.grad) <= 1e-4
+    assert U.relerr(db.cpu(), br.grad) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------- GN backward
+def _gn_forward_state(x, gamma, beta, dt):
+    """Runs stats -> gn_finalize on the device for x (N,C,H,W); returns device tensors."""
+    n, c, h, w = x.shape
+    xr = U.rounded(x, dt).double().view(n, 8, -1)
+    stats = torch.stack([xr.sum(2), (xr * xr).sum(2)], -1).contiguous().to(U.DEV)
+    scale, shift = torch.empty(n * c, device=U.DEV), torch.empty(n * c, device=U.DEV)
+    mr = torch.empty(n * 16, device=U.DEV)
+    L.call("mrisr_gn_finalize", stats.data_ptr(), gamma.to(U.DEV).data_ptr(), beta.to(U.DEV).data_ptr(), scale.data_ptr(),
+           shift.data_ptr(), mr.data_ptr(), n, c, 8, float((c // 8) * h * w), 1e-5, U.stream())
+    return scale, shift, mr
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("mode", ["direct", "pool+direct", "up", "shuffled"])
+def test_act_backward(dt, mode):
+    n, c, h, w = 2, 32, 18, 26
+    x = rnd(n, c, h, w, seed=70)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=71), 0.1 * rnd(c, seed=72)
+    scale, shift, mr = _gn_forward_state(x, gamma, beta, dt)
+    # reference: autograd through group_norm + leaky_relu + consumer transforms
+    xr = U.rounded(x, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    act = F.leaky_relu(F.group_norm(xr, 8, gr, br, 1e-5), 0.2)
+    cons, keep, loss = [], [], 0
+    if mode in ("direct", "pool+direct", "shuffled"):
+        da = rnd(n, c + 16, h + 1, w + 2, seed=73)        # producer sits at channels [16, 16+c), offset (1, 2)... pad offs (0,1)
+        loss = loss + (F.pad(act, [1, 1, 0, 1]) * U.rounded(da, dt)[:, 16:]).sum()
+        cons.append((da, c + 16, 16, h + 1, w + 2, L.SP_NONE, 0, 1))
+    if mode == "pool+direct":
+        dp = rnd(n, c, h // 2, w // 2, seed=74)
+        loss = loss + (F.max_pool2d(act, 2) * U.rounded(dp, dt)).sum()
+        cons.append((dp, c, 0, h // 2, w // 2, L.SP_POOL2, 0, 0))
+    if mode == "up":
+        du = rnd(n, c, 2 * h, 2 * w, seed=75)
+        loss = loss + (F.interpolate(act, scale_factor=2, mode="bilinear", align_corners=True) * U.rounded(du, dt)).sum()
+        cons.append((du, c, 0, 2 * h, 2 * w, L.SP_UP2, 0, 0))
+    loss.backward()
+    carr = (L.Consumer * 2)()
+    for i, (da, ctot, coff, ch, cw, sp, oy, ox) in enumerate(cons):
+        dd = U.nhwc(da, dt)
+        keep.append(dd)
+        carr[i].da, carr[i].C_total, carr[i].c_off, carr[i].H, carr[i].W = dd.data_ptr(), ctot, coff, ch, cw
+        carr[i].spatial, carr[i].off_y, carr[i].off_x, carr[i].weight_mode = sp, oy, ox, 0
+    xd = U.nhwc(x, dt)
+    g = torch.empty_like(xd)
+    red = torch.zeros(n * c * 2, device=U.DEV)
+    L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), len(cons), carr,
+           None, g.data_ptr(), red.data_ptr(), n, h, w, c, 8, U.stream())
+    dgam, dbet, coef = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.empty(3 * n * c, device=U.DEV)
+    L.call("mrisr_act_bwd_finalize", red.data_ptr(), gamma.to(U.DEV).data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+           coef.data_ptr(), n, c, 8, float((c // 8) * h * w), U.stream())
+    if mode == "shuffled":
+        dx = torch.empty((n, h // 2, w // 2, 4 * c), dtype=U.tdt(dt), device=U.DEV)
+        L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PIXEL_SHUFFLE2, U.stream())
+        got = F.pixel_shuffle(U.nchw(dx), 2)
+    else:
+        dx = torch.empty_like(xd)
+        L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PLAIN, U.stream())
+        got = U.nchw(dx)
+    torch.cuda.synchronize()
+    tol = 3e-4 if dt == L.F32 else 2e-2
+    assert U.relerr(got, xr.grad) <= tol
+    assert U.relerr(dgam.cpu(), gr.grad) <= tol
+    assert U.relerr(dbet.cpu(), br.grad) <= tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_blend_alpha_grad_and_channel_sum(dt):
+    n, c, h, w = 2, 16, 14, 22
+    x0, x1, da = rnd(n, c, h, w, seed=80), rnd(n, c, h, w, seed=81), rnd(n, c, h, w, seed=82)
+    (s0, t0), (s1, t1) = gn_affine(n, c, 83), gn_affine(n, c, 84)
+    alpha = torch.tensor(0.4, requires_grad=True)
+    a0 = F.leaky_relu(U.rounded(x0, dt) * s0.view(n, c, 1, 1) + t0.view(n, c, 1, 1), 0.2)
+    a1 = F.leaky_relu(U.rounded(x1, dt) * s1.view(n, c, 1, 1) + t1.view(n, c, 1, 1), 0.2)
+    sg = torch.sigmoid(alpha)
+    ((sg * a0 + (1 - sg) * a1) * U.rounded(da, dt)).sum().backward()
+    dal = torch.zeros(1, device=U.DEV)
+    dev = [U.nhwc(da, dt), U.nhwc(x0, dt), s0.to(U.DEV), t0.to(U.DEV), U.nhwc(x1, dt), s1.to(U.DEV), t1.to(U.DEV), alpha.detach().reshape(1).to(U.DEV)]
+    L.call("mrisr_blend_alpha_grad", dt, *[t.data_ptr() for t in dev], dal.data_ptr(), n, h, w, c, U.stream())
+    assert abs(dal.item() - alpha.grad.item()) <= 1e-4 * abs(alpha.grad.item()) + 1e-5
+    cs = torch.zeros(c, device=U.DEV)
+    L.call("mrisr_channel_sum", dt, dev[0].data_ptr(), cs.data_ptr(), n * h * w, c, U.stream())
+    assert U.relerr(cs.cpu(), U.rounded(da, dt).sum((0, 2, 3))) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------- adam / cast
+def test_adam_matches_reference():
+    from oracle.train_ref import AdamRef
+    g = torch.Generator().manual_seed(90)
+    p0 = torch.randn(10007, generator=g)
+    sd = {"p": p0.clone()}
+    opt = AdamRef(sd, lr=1e-3, weight_decay=1e-2)
+    pd, m, v = p0.to(U.DEV), torch.zeros(10008, device=U.DEV)[:10007], torch.zeros(10008, device=U.DEV)[:10007]
+    pd = torch.zeros(10008, device=U.DEV)[:10007].copy_(p0)
+    for step in range(1, 4):
+        gr = torch.randn(10007, generator=g)
+        opt.step(sd, {"p": gr * 0.5})
+        gd = torch.zeros(10008, device=U.DEV)[:10007].copy_(gr)
+        L.call("mrisr_adam_step", pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 10007, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, 0.5, U.stream())
+        assert (pd.cpu() - sd["p"]).abs().max().item() <= 2e-6
+
+
+def test_error_reporting():
+    d = L.ConvDesc()
+    d.dtype, d.ksize, d.nsrc = 7, 3, 1
+    rc = L.load().mrisr_conv_forward(C.byref(d), None)
+    assert rc == -3 and b"dtype" in L.load().mrisr_last_error()
+    with pytest.raises(RuntimeError, match="adam_step"):
+        L.call("mrisr_adam_step", None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None)

@@ -1,0 +1,186 @@
+"""End-to-end parity (GPU): UNetSuperRes / CombinedLoss / SSIM / FusedAdam through the public Python
+mirror (which binds the C-ABI) against the CPU oracle and the committed reference goldens.
+
+Tolerances (north_star): fp32 path <= 1e-3 relative on the forward output; bf16 path: PSNR / SSIM
+of the output vs the fp32 reference output agree to 3 significant figures with the reference's.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mri_superresolution_amd.models.unet_model import UNetSuperRes       # noqa: E402
+from mri_superresolution_amd.optim import FusedAdam                       # noqa: E402
+from mri_superresolution_amd.utils.losses import SSIM, CombinedLoss, ssim  # noqa: E402
+from oracle.inputs import make_pair                                       # noqa: E402
+from oracle import losses_ref                                             # noqa: E402
+from oracle.train_ref import loss_and_grads, train_steps                  # noqa: E402
+from oracle.unet_ref import formula_state_dict, unet_forward              # noqa: E402
+
+CASES = ["unet_f16_n2_32x32", "unet_f16_n1_48x40", "unet_f16_n1_50x70_odd", "unet_f32_n1_64x64"]
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _model(f, seed, dtype):
+    m = UNetSuperRes(1, 1, f)
+    m.load_state_dict(formula_state_dict(f, seed))
+    return m.cuda().set_compute_dtype(dtype)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_fp32_matches_reference_golden(golden_dir, case):
+    g = _golden(golden_dir, case)
+    f, n, h, w, seed = (int(v) for v in g["meta"])
+    m = _model(f, seed, torch.float32).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["low"]).cuda()).cpu()
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape
+    rel = ((out - ref).abs() / ref.abs().clamp_min(1e-3)).max().item()
+    assert rel <= 1e-3, f"max rel err {rel:.3e}"
+    assert (out - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("case", ["unet_f16_n2_32x32", "unet_f32_n1_64x64"])
+def test_forward_bf16_psnr_ssim_3sf(golden_dir, case):
+    g = _golden(golden_dir, case)
+    f, n, h, w, seed = (int(v) for v in g["meta"])
+    m = _model(f, seed, torch.bfloat16).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["low"]).cuda()).cpu()
+    ref, high = torch.from_numpy(g["out"]), torch.from_numpy(g["high"])
+    # PSNR / SSIM of the network output against the HR target, reference vs this build: 3 s.f.
+    for fn in (losses_ref.psnr, lambda a, b: float(losses_ref.ssim(a, b))):
+        a, b = fn(out, high), fn(ref, high)
+        assert abs(a - b) <= 5e-3 * abs(b), (a, b)
+    assert losses_ref.psnr(out, ref) >= 40.0        # bf16 output vs fp32 reference output
+
+
+@pytest.mark.parametrize("case", ["unet_f16_n2_32x32", "unet_f16_n1_50x70_odd"])
+@pytest.mark.parametrize("ssim_weight", [0.0, 0.4])
+def test_loss_and_gradients_fp32(golden_dir, case, ssim_weight):
+    g = _golden(golden_dir, case)
+    f, n, h, w, seed = (int(v) for v in g["meta"])
+    sd = formula_state_dict(f, seed)
+    low, high = make_pair(n, h, w, seed)
+    _, ref_loss, ref_grads = loss_and_grads(sd, low, high, ssim_weight)
+    if f"loss/{ssim_weight}" in g.files:        # the oracle itself is pinned to the reference on CPU
+        assert abs(float(ref_loss) - float(g[f"loss/{ssim_weight}"])) <= 2e-6
+    m = _model(f, seed, torch.float32).train()
+    crit = CombinedLoss(ssim_weight=ssim_weight, device=torch.device("cuda"))
+    loss = crit(m(low.cuda()), high.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(ref_loss)) <= 2e-5
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        r = ref_grads[k]
+        err = (p.grad.cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-7)
+        worst = max(worst, err)
+        assert err <= 2e-3, f"{k}: rel err {err:.3e}"
+    print(f"worst grad rel err {worst:.2e}")
+
+
+def test_gradients_bf16_close(golden_dir):
+    f, n, h, w, seed = 16, 2, 32, 32, 1
+    sd = formula_state_dict(f, seed)
+    low, high = make_pair(n, h, w, seed)
+    _, ref_loss, ref_grads = loss_and_grads(sd, low, high, 0.4)
+    m = _model(f, seed, torch.bfloat16).train()
+    loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(m(low.cuda()), high.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(ref_loss)) <= 5e-3 * float(ref_loss)
+    for k, p in m.named_parameters():
+        r = ref_grads[k].flatten().double()
+        gq = p.grad.cpu().flatten().double()
+        cos = float((gq * r).sum() / (gq.norm() * r.norm()).clamp_min(1e-30))
+        assert cos >= 0.98, f"{k}: cosine {cos:.4f}"
+        assert abs(float(gq.norm() / r.norm().clamp_min(1e-30)) - 1.0) <= 0.1, k
+
+
+def test_ssim_and_combined_loss_match_reference_golden(golden_dir):
+    g = _golden(golden_dir, "ssim")
+    metric = SSIM()
+    for i in range(5):
+        a, b = torch.from_numpy(g[f"a{i}"]).cuda(), torch.from_numpy(g[f"b{i}"]).cuda()
+        assert abs(ssim(a, b).item() - float(g[f"ssim{i}"])) <= 2e-6
+        assert abs(metric(a, a).item() - float(g[f"ssim_self{i}"])) <= 2e-6
+        assert np.abs(ssim(a, b, size_average=False).cpu().numpy() - g[f"ssim_ps{i}"]).max() <= 2e-6
+        x = a.clone().requires_grad_(True)
+        loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(x, b)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"closs{i}"])) <= 2e-6
+        ref = g[f"cgrad{i}"]
+        assert np.abs(x.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+        # bare ssim() gradient vs the oracle's autograd
+        x2 = a.clone().requires_grad_(True)
+        ssim(x2, b).backward()
+        xr = torch.from_numpy(g[f"a{i}"]).requires_grad_(True)
+        losses_ref.ssim(xr, torch.from_numpy(g[f"b{i}"])).backward()
+        assert (x2.grad.cpu() - xr.grad).abs().max().item() <= 2e-4 * xr.grad.abs().max().item()
+
+
+def test_loss_api_errors_and_edges():
+    for bad in ((-0.1, 0.0), (0.0, 1.5), (0.7, 0.6)):
+        with pytest.raises(ValueError):
+            CombinedLoss(ssim_weight=bad[0], perceptual_weight=bad[1])
+    with pytest.raises(RuntimeError):
+        ssim(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))      # CPU tensors: no fallback
+    a = torch.rand(2, 3, 20, 24, device="cuda")                          # multi-channel = depthwise windows
+    b = (a + 0.1 * torch.rand_like(a)).clamp(0, 1)
+    assert abs(ssim(a, b).item() - float(losses_ref.ssim(a.cpu(), b.cpu()))) <= 2e-6
+    ident = ssim(a, a).item()
+    assert abs(ident - 1.0) <= 1e-6
+
+
+def test_train3_matches_reference_golden(golden_dir):
+    g = _golden(golden_dir, "train3")
+    f, n, h, w, seed = (int(v) for v in g["meta"])
+    m = _model(f, seed, torch.float32).train()
+    opt = FusedAdam(m, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    crit = CombinedLoss(ssim_weight=float(g["ssim_weight"]), device=torch.device("cuda"))
+    metric = SSIM()
+    losses, ssims = [], []
+    for step in range(3):          # order of scripts/train.py:301-323
+        low, high = (t.cuda() for t in make_pair(n, h, w, seed * 10 + step))
+        opt.zero_grad(set_to_none=True)
+        out = m(low)
+        loss = crit(out, high)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        with torch.no_grad():
+            ssims.append(metric(out, high).item())
+    assert np.abs(np.array(losses) - g["losses"]).max() <= 1e-4, (losses, g["losses"])
+    assert np.abs(np.array(ssims) - g["ssims"]).max() <= 1e-4
+    sd = m.state_dict()
+    for k in ("alpha", "inc.double_conv.1.weight", "final_conv.3.bias", "up2.up.2.bias"):
+        ref = g["param/" + k]
+        assert np.abs(sd[k].cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3), k
+    # optimizer checkpoint is in torch.optim.Adam's layout
+    osd = opt.state_dict()
+    assert len(osd["state"]) == 64 and set(osd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_grad_accumulation_and_eval_mode():
+    f, seed = 16, 1
+    low, high = (t.cuda() for t in make_pair(1, 16, 24, 9))
+    m = _model(f, seed, torch.float32).train()
+    crit = CombinedLoss(ssim_weight=0.3, device=torch.device("cuda"))
+    crit(m(low), high).backward()
+    g1 = m.flat_grads.clone()
+    crit(m(low), high).backward()          # second backward accumulates, like autograd
+    assert torch.allclose(m.flat_grads, 2 * g1, rtol=1e-4, atol=1e-7)
+    m.zero_grad(set_to_none=True)
+    crit(m(low), high).backward()
+    assert torch.allclose(m.flat_grads, g1, rtol=1e-4, atol=1e-7)
+    m.eval()
+    with torch.no_grad():
+        o1 = m(low)
+    assert o1.shape == (1, 1, 32, 48) and o1.min() >= 0 and o1.max() <= 1 and not o1.requires_grad
