@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 2-D MRI slices/s of the U-Net super-resolution TRAIN step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): UNetSuperRes base_filters=64, input 256x256 -> output 512x512,
+batch 16 per GPU, bf16 MFMA compute (fp32 accumulate / statistics / masters), loss L1 + SSIM(0.4).
+One step = the reference loop body (scripts/train.py:301-323): zero_grad -> forward -> CombinedLoss ->
+backward (+ bucketed RCCL all-reduce when N>1) -> fused Adam -> no-grad SSIM metric.  Inputs are
+synthetic U[0,1) tensors resident in HBM; weights are the reference's Kaiming init.  The per-step
+`.item()` host syncs of the reference are not reproduced (nothing is read back inside the timed region).
+
+Prints ONE JSON line on rank 0 (see the repo prompt for the schema) with two extra objects:
+`roofline` for the dominant kernel (largest total time among the live-timed convolution kernels) and
+`cpu_baseline` (the oracle port timed on this box's host cores, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "2D MRI slices/sec (train fwd+bwd) 256×256 U-Net; PSNR/SSIM vs ref"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="slices per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, default=256, help="network input H=W (output is 2x)")
+    ap.add_argument("--base-filters", type=int, default=64)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--ssim-weight", type=float, default=0.4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="eval forward only (inference metric; not the headline)")
+    return ap.parse_args()
+
+
+def cpu_baseline(base_filters, size, ssim_weight):
+    """Oracle port (same aten ops as the reference) on the host cores: bounded sample of the SAME
+    workload shapes (batch 2 instead of 16, 1 warm-up + 3 timed steps)."""
+    from oracle.train_ref import cpu_train_step_fn
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    batch = 2
+    step = cpu_train_step_fn(base_filters, batch, size, size, ssim_weight, threads=threads)
+    step()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * n / dt, 4), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle torch-CPU fp32 train step, base_filters={base_filters}, {size}x{size}->{2 * size}x{2 * size}, "
+                      f"batch {batch}, L1+SSIM({ssim_weight}), 1 warm-up + {n} timed steps, {dt / n * 1e3:.0f} ms/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mri_superresolution_amd.engine import KernelTimer
+    from mri_superresolution_amd.models.unet_model import UNetSuperRes
+    from mri_superresolution_amd.optim import FusedAdam
+    from mri_superresolution_amd.parallel import DataParallel
+    from mri_superresolution_amd.utils.losses import SSIM, CombinedLoss
+    from oracle.unet_ref import unet_flops_fwd        # FLOP formula only
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = UNetSuperRes(1, 1, args.base_filters).to(dev).set_compute_dtype(dtype).train()
+    opt = FusedAdam(model, lr=1e-4, weight_decay=1e-5)
+    crit = CombinedLoss(ssim_weight=args.ssim_weight, device=dev)
+    metric = SSIM(device=dev)
+    dp = None
+    if world > 1:
+        dp = DataParallel(model)
+        opt.grad_scale = 1.0 / world
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    B, S = args.batch, args.size
+    low = torch.rand(B, 1, S, S, generator=g).to(dev)
+    high = torch.rand(B, 1, 2 * S, 2 * S, generator=g).to(dev)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        out = model(low)
+        loss = crit(out, high)
+        loss.backward()
+        if dp is not None:
+            dp.finish_gradients()
+        opt.step()
+        with torch.no_grad():
+            metric(out, high)
+        return loss
+
+    def fwd_step():
+        with torch.no_grad():
+            return model(low)
+
+    if args.forward_only:
+        model.eval()
+    step = fwd_step if args.forward_only else train_step
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = model._engine.timer = KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    model._engine.timer = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        f_fwd = unet_flops_fwd(args.base_filters, S, S)
+        flops_slice = f_fwd if args.forward_only else 3.0 * f_fwd
+        rec = {
+            "metric": METRIC if not args.forward_only else "2D MRI slices/sec (eval forward) 256×256 U-Net",
+            "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"UNetSuperRes base_filters={args.base_filters} depth=4, {S}x{S} slices -> {2 * S}x{2 * S}, "
+                                   f"batch={B}/GPU {args.dtype}, L1+SSIM({args.ssim_weight}), "
+                                   + ("eval forward" if args.forward_only else "train step fwd+bwd+Adam+SSIM metric"),
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "conv_flops_per_slice": flops_slice,
+                       "model_tflops": round(value * flops_slice / 1e12, 2),
+                       "frac_of_mfma_peak": round(value * flops_slice / 1e12 / (world * MFMA_PEAK_TFLOPS[args.dtype]), 4)},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            if summ:
+                name, dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+                peak = MFMA_PEAK_TFLOPS[args.dtype]
+                rec["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(dom["tflops"], 2), "peak": peak,
+                                   "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+                                   "launches": dom["launches"], "us_per_launch": round(dom["ms_per_launch"] * 1e3, 2),
+                                   "flops_per_launch": dom["flops_per_launch"]}
+                rec["kernels"] = {k: {"launches": v["launches"], "us_per_launch": round(v["ms_per_launch"] * 1e3, 2),
+                                      "tflops": round(v["tflops"], 2), "share_of_step": round(v["total_ms"] / (ms * args.steps), 4)}
+                                  for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
+            rec["cpu_baseline"] = cpu_baseline(args.base_filters, S, args.ssim_weight)
+        rec["loss"] = float(last) if not args.forward_only else None
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

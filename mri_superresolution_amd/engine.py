@@ -73,6 +73,45 @@ class Layer:
     offs: list = field(default_factory=list)
 
 
+class KernelTimer:
+    """Optional live timing of the convolution launches with HIP events on the launch stream
+    (bench.py roofline).  Launches are grouped by kernel symbol (= template instantiation), the same
+    grouping `rocprofv3 --kernel-trace --stats` reports."""
+
+    def __init__(self):
+        self.records = []          # (name, flops, start_event, end_event)
+        self.enabled = True
+
+    def launch(self, name: str, flops: float, fn):
+        if not self.enabled:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.append((name, flops, a, b))
+
+    def summary(self):
+        """name -> dict(launches, flops_per_launch, ms_per_launch, tflops); call after a device sync."""
+        agg = {}
+        for name, flops, a, b in self.records:
+            e = agg.setdefault(name, [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += flops
+            e[2] += a.elapsed_time(b)
+        return {k: {"launches": n, "flops_per_launch": fl / n, "ms_per_launch": ms / n,
+                    "total_ms": ms, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+                for k, (n, fl, ms) in agg.items()}
+
+
+def conv_kernel_name(kind: str, dt: int, cout: int, spatial: int, ks: int) -> str:
+    """Mirrors the dispatch in csrc/conv_fwd.hip / conv_wgrad.hip."""
+    t = "bf16" if dt == L.BF16 else "f32"
+    if kind == "wgrad":
+        return f"conv_wgrad_kernel<{t},SP{spatial},K{ks}>"
+    return f"conv_igemm_kernel<{t},BN{64 if cout >= 64 else 32},SP{spatial},K{ks}>"
+
+
 class UNetEngine:
     """Executes UNetSuperRes on one GPU.  ``params``: dict key -> fp32 tensor (conv weights in
     channels_last storage, i.e. physically [Cout][kh][kw][Cin]); ``grads``: same keys."""
@@ -125,6 +164,13 @@ class UNetEngine:
         self.head_in = fc
         self._packed: Dict[tuple, torch.Tensor] = {}
         self._pack_versions: Dict[tuple, int] = {}
+        self.timer: Optional[KernelTimer] = None
+
+    def _launch(self, kind, dt, N, H, W, cin, cout, spatial, ks, fn):
+        if self.timer is None:
+            return fn()
+        flops = 2.0 * N * H * W * cin * cout * ks * ks
+        self.timer.launch(conv_kernel_name(kind, dt, cout, spatial, ks), flops, fn)
 
     # ------------------------------------------------------------------ weights
     def _packed_weight(self, layer: Layer, params, dt: int, flip: int, stream, force: bool = False):
@@ -227,7 +273,8 @@ class UNetEngine:
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
             d.out = o.raw.data_ptr()
             d.stats = o.stats.data_ptr()
-            L.call("mrisr_conv_forward", C.byref(d), st)
+            self._launch("fwd", dt, N, vh, vw, layer.cin, layer.cout, layer.srcs[0].spatial, layer.ks,
+                         lambda: L.call("mrisr_conv_forward", C.byref(d), st))
             finalize(o)
 
         hn = self.head_in
@@ -308,7 +355,9 @@ class UNetEngine:
             o = layer.out
             dy = node_backward(o)
             d = self._desc(layer, dt, N, params)
-            L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(), grads[layer.name + ".weight"].data_ptr(), st)
+            self._launch("wgrad", dt, N, layer.H, layer.W, layer.cin, layer.cout, layer.srcs[0].spatial, layer.ks,
+                         lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
+                                        grads[layer.name + ".weight"].data_ptr(), st))
             if layer.bias:
                 L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
                        N * layer.H * layer.W, layer.cout, st)
@@ -323,7 +372,8 @@ class UNetEngine:
             dd.wpacked = self._packed_weight(layer, params, dt, 1, st, force=True).data_ptr()
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
-            L.call("mrisr_conv_forward", C.byref(dd), st)
+            self._launch("dgrad", dt, N, layer.H, layer.W, layer.cout, layer.cin, L.SP_NONE, layer.ks,
+                         lambda: L.call("mrisr_conv_forward", C.byref(dd), st))
             if layer.combine == L.COMBINE_BLEND:
                 a, b = layer.srcs[0].node, layer.srcs[1].node
                 L.call("mrisr_blend_alpha_grad", dt, dain.data_ptr(), a.raw.data_ptr(), a.scale.data_ptr(),

@@ -106,7 +106,7 @@ def case_ssim():
     print("ssim", [float(rec[f"ssim{i}"]) for i in range(5)])
 
 
-def case_train3(f=16, n=2, h=32, w=32, seed=3, ssim_weight=0.4):
+def case_train3(f=16, n=2, h=32, w=32, seed=3, ssim_weight=0.4, tag="train3"):
     """Three optimiser steps with the reference model + CombinedLoss + torch.optim.Adam in the
     order of scripts/train.py:301-323 (train.py itself needs torchvision.transforms)."""
     model = ref_model(f, seed).train()
@@ -129,8 +129,8 @@ def case_train3(f=16, n=2, h=32, w=32, seed=3, ssim_weight=0.4):
            "lr": np.float64(1e-3), "weight_decay": np.float64(1e-5)}
     for k, p in model.named_parameters():
         rec["param/" + k] = digest(p.detach()) if p.numel() > 512 else p.detach().numpy().copy()
-    np.savez_compressed(os.path.join(OUT, "train3.npz"), **rec)
-    print("train3 losses", losses)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
+    print(tag, "losses", losses)
 
 
 def main():
@@ -143,6 +143,7 @@ def main():
     case_forward_backward("unet_f32_n1_64x64", 32, 1, 64, 64, seed=5, ssim_ws=(0.4,))
     case_ssim()
     case_train3()
+    case_train3(ssim_weight=0.0, tag="train3_l1")
 
 
 if __name__ == "__main__":

@@ -191,8 +191,9 @@ def test_head_forward_backward(dt):
     ref.backward(dout)
     da = torch.empty((n, h, w, c), dtype=U.tdt(dt), device=U.DEV)
     dw, db = torch.zeros(c, device=U.DEV), torch.zeros(1, device=U.DEV)
+    doutd = dout.to(U.DEV)
     L.call("mrisr_head_backward", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wd.data_ptr(), out.data_ptr(),
-           dout.to(U.DEV).data_ptr(), da.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, w, c, U.stream())
+           doutd.data_ptr(), da.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, w, c, U.stream())
     assert U.relerr(U.nchw(da), act.grad) <= TOL_OUT[dt]
     assert U.relerr(dw.cpu(), wr.grad) <= 1e-4
     assert U.relerr(db.cpu(), br.grad) <= 1e-4
@@ -206,8 +207,10 @@ def _gn_forward_state(x, gamma, beta, dt):
     stats = torch.stack([xr.sum(2), (xr * xr).sum(2)], -1).contiguous().to(U.DEV)
     scale, shift = torch.empty(n * c, device=U.DEV), torch.empty(n * c, device=U.DEV)
     mr = torch.empty(n * 16, device=U.DEV)
-    L.call("mrisr_gn_finalize", stats.data_ptr(), gamma.to(U.DEV).data_ptr(), beta.to(U.DEV).data_ptr(), scale.data_ptr(),
+    gd, bd = gamma.to(U.DEV), beta.to(U.DEV)          # keep the device copies alive across the launch
+    L.call("mrisr_gn_finalize", stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), scale.data_ptr(),
            shift.data_ptr(), mr.data_ptr(), n, c, 8, float((c // 8) * h * w), 1e-5, U.stream())
+    torch.cuda.synchronize()
     return scale, shift, mr
 
 
@@ -248,7 +251,8 @@ def test_act_backward(dt, mode):
     L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), len(cons), carr,
            None, g.data_ptr(), red.data_ptr(), n, h, w, c, 8, U.stream())
     dgam, dbet, coef = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.empty(3 * n * c, device=U.DEV)
-    L.call("mrisr_act_bwd_finalize", red.data_ptr(), gamma.to(U.DEV).data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+    gdev = gamma.to(U.DEV)
+    L.call("mrisr_act_bwd_finalize", red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
            coef.data_ptr(), n, c, 8, float((c // 8) * h * w), U.stream())
     if mode == "shuffled":
         dx = torch.empty((n, h // 2, w // 2, 4 * c), dtype=U.tdt(dt), device=U.DEV)

@@ -80,8 +80,9 @@ def test_ssim_matches_reference(golden_dir):
         assert np.abs(x.grad.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
-def test_train3_matches_reference(golden_dir):
-    g = _load(golden_dir, "train3")
+@pytest.mark.parametrize("name", ["train3", "train3_l1"])
+def test_train3_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
     f, n, h, w, seed = (int(v) for v in g["meta"])
     batches = [make_pair(n, h, w, seed * 10 + s) for s in range(3)]
     log, sd = train_steps(formula_state_dict(f, seed), batches, float(g["ssim_weight"]),
