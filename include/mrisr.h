@@ -107,6 +107,18 @@ int mrisr_gn_finalize(const double* stats, const float* gamma, const float* beta
                       float* shift, float* meanrstd, int N, int C, int groups, double count,
                       float eps, void* stream);
 
+/* out [N][H/2][W/2][C] = MaxPool2d(2)(LeakyReLU(x*scale+shift))  (unet_model.py:52): materialised pooled
+ * activation, so the encoder convolutions read a plain tensor.                                            */
+int mrisr_norm_pool2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
+                     int H, int W, int C, void* stream);
+/* z [N][2h][2w][C] = bilinear x2 (align_corners=True) of z_low [N][h][w][C], plus GroupNorm statistics of z
+ * (stats [N][groups][2] double, accumulated; may be NULL).  With mrisr_conv_forward on the low-resolution
+ * tensor this evaluates nn.Upsample -> nn.Conv2d(1x1) (unet_model.py:71-72) as conv -> upsample.           */
+int mrisr_upsample2_stats(int dtype, const void* z_low, void* z, double* stats, int N, int h, int w, int C,
+                          int groups, void* stream);
+/* adjoint of the above interpolation: dz [N][2h][2w][C] -> dz_low [N][h][w][C]                              */
+int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, int N, int h, int w, int C, void* stream);
+
 /* consumer of an activation in the backward pass */
 typedef struct {
     const void* da;       /* NHWC gradient w.r.t. the consumer conv's (virtual) input           */

@@ -76,7 +76,7 @@ template <typename T> __device__ __forceinline__ void store_vec16(T* p, const Ve
     *reinterpret_cast<decltype(r.v)*>(p) = r.v;
 }
 
-__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : LRELU_SLOPE * x; }
+__device__ __forceinline__ float lrelu(float x) { return fmaxf(x, LRELU_SLOPE * x); }   // slope < 1
 
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {

@@ -4,7 +4,7 @@
 #pragma once
 #include "common.h"
 
-constexpr int kConvThreads = 256;   // 4 waves
+constexpr int kConvThreads = 256;   // 4 waves (wgrad; one half of the forward kernel's 8-wave workgroup)
 constexpr int kRowBytes = 64;       // bytes of K (input channels) per LDS row and cin-chunk
 constexpr int kMaxHaloIter = 6;     // ceil(340 / 64): tiles 8x32, 16x16, 32x8 (+halo)
 
@@ -14,6 +14,12 @@ __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * kRowBytes + ((chunk ^ swz(row)) << 4);
 }
+
+// Forward halo image: 64 B of channels per pixel in 80-byte rows (16 B pad).  Linear in the row index, so
+// the 9 tap offsets are wave-uniform scalars added to one per-lane base, and 16 consecutive rows cover
+// all 16 sixteen-byte bank slots (5*i mod 16 is a bijection): conflict-free ds_read_b128 fragments.
+constexpr int kHaloRowBytes = 80;
+__device__ __forceinline__ int halo_off(int row, int chunk) { return row * kHaloRowBytes + (chunk << 4); }
 
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
 static inline int conv_bk(int dtype) { return dtype == MRISR_BF16 ? 32 : 16; }
@@ -38,7 +44,27 @@ struct ConvParams {
     int nsrc, combine, out_mode, groups, relu_out;
     int tw_log2, th, tiles_x, tiles_y, ncb, nchunks;
     int ksplit;       // wgrad only
+    int ws;           // forward: all cin chunks of the weight image stay resident in LDS
+    int ntiles, tiles_per_block;   // forward: persistent blocks own contiguous tile ranges
+    int dbg;          // tuning ablations (env MRISR_DEBUG): 1 no stores, 2 no LDS commit, 4 no global loads, 8 no MFMA
 };
+
+// hipcc re-loads kernel arguments with s_load + s_waitcnt at every use inside long loops (they are "free" to
+// rematerialise); pinning the hot ones as opaque scalars keeps them in SGPRs instead.
+#define PIN_F(q, src, f) { auto v__ = (src).f; asm volatile("" : "+s"(v__)); (q).f = v__; }
+__device__ __forceinline__ ConvParams pin_params(const ConvParams& in) {
+    ConvParams q = in;
+    PIN_F(q, in, H) PIN_F(q, in, W) PIN_F(q, in, Cout) PIN_F(q, in, N) PIN_F(q, in, nchunks) PIN_F(q, in, tw_log2)
+    PIN_F(q, in, th) PIN_F(q, in, tiles_x) PIN_F(q, in, tiles_y) PIN_F(q, in, nsrc) PIN_F(q, in, dbg)
+    PIN_F(q, in, groups) PIN_F(q, in, relu_out) PIN_F(q, in, out) PIN_F(q, in, stats) PIN_F(q, in, bias)
+    PIN_F(q, in, src[0].ptr) PIN_F(q, in, src[0].scale) PIN_F(q, in, src[0].shift) PIN_F(q, in, src[0].C)
+    PIN_F(q, in, src[0].H) PIN_F(q, in, src[0].W) PIN_F(q, in, src[0].mode) PIN_F(q, in, src[0].off_y)
+    PIN_F(q, in, src[0].off_x)
+    PIN_F(q, in, src[1].ptr) PIN_F(q, in, src[1].scale) PIN_F(q, in, src[1].shift) PIN_F(q, in, src[1].C)
+    PIN_F(q, in, src[1].H) PIN_F(q, in, src[1].W) PIN_F(q, in, src[1].mode) PIN_F(q, in, src[1].off_y)
+    PIN_F(q, in, src[1].off_x)
+    return q;
+}
 
 // Per-thread precomputed geometry of the halo pixels this thread stages (same for every cin chunk).
 template <int SPATIAL> struct HaloGeom;
@@ -77,14 +103,24 @@ __device__ __forceinline__ void transform_f(const Vec16<T>& v, float* o, int mod
     }
 }
 
-// Computes the geometry of halo pixel `hp` of the tile at (n, ty0, tx0); halo width hw, conv padding pad.
+// Computes the geometry of halo pixel `hp` = (hy, hx) of the tile at (n, ty0, tx0); conv padding pad.
+template <int SPATIAL>
+__device__ __forceinline__ void halo_geom_yx(HaloGeom<SPATIAL>& g, int i, int hy, int hx, bool slot_ok,
+                                             int pad, int n, int ty0, int tx0, const ConvParams& p);
+
 template <int SPATIAL>
 __device__ __forceinline__ void halo_geom_init(HaloGeom<SPATIAL>& g, int i, int hp, int npix_halo, int hw,
                                                int pad, int n, int ty0, int tx0, const ConvParams& p) {
-    int o0 = -1;
     const int hy = hp / hw, hx = hp - hy * hw;
+    halo_geom_yx<SPATIAL>(g, i, hy, hx, hp < npix_halo, pad, n, ty0, tx0, p);
+}
+
+template <int SPATIAL>
+__device__ __forceinline__ void halo_geom_yx(HaloGeom<SPATIAL>& g, int i, int hy, int hx, bool slot_ok,
+                                             int pad, int n, int ty0, int tx0, const ConvParams& p) {
+    int o0 = -1;
     const int y = ty0 + hy - pad, x = tx0 + hx - pad;
-    const bool inside = hp < npix_halo && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const bool inside = slot_ok && y >= 0 && y < p.H && x >= 0 && x < p.W;
     const SrcDev& s0 = p.src[0];
     if constexpr (SPATIAL == MRISR_SP_NONE) {
         int o1 = -1;
@@ -214,9 +250,9 @@ __device__ __forceinline__ int lds_off128(int row, int sub, int chunk) {
 // image, ROWB = 128: wgrad image, `sub` selects the 64-B half).
 template <typename T, int SPATIAL, int ROWB = 64, int BATCH = kMaxHaloIter>
 __device__ __forceinline__ void stage_halo(char* lds_halo, const HaloGeom<SPATIAL>& g, int kc, int n,
-                                           int npix_halo, float blend_a, const ConvParams& p, int sub = 0) {
+                                           int npix_halo, float blend_a, const ConvParams& p, int sub = 0,
+                                           int t = threadIdx.x) {
     constexpr int VEC = Vec16<T>::N;
-    const int t = threadIdx.x;
     const int chunk = t & 3;
     const int c0 = kc * (kRowBytes / (int)sizeof(T)) + chunk * VEC;   // channel in the conv input
     int which = 0, cs = c0;
@@ -235,7 +271,7 @@ __device__ __forceinline__ void stage_halo(char* lds_halo, const HaloGeom<SPATIA
             const Vec16<T> v = halo_load<T, SPATIAL>(g, i, c0, p, sc0, sh0, sc0, sh0, blend_a, 0, cs);
             if (hp < npix_halo)
                 *reinterpret_cast<decltype(v.v)*>(
-                    lds_halo + (ROWB == 64 ? lds_off(hp, chunk) : lds_off128(hp, sub, chunk))) = v.v;
+                    lds_halo + (ROWB == 64 ? halo_off(hp, chunk) : lds_off128(hp, sub, chunk))) = v.v;
             __builtin_amdgcn_sched_barrier(0);   // one gather (4 loads) in flight: keeps VGPRs for the accumulators
         }
         return;
@@ -266,7 +302,7 @@ __device__ __forceinline__ void stage_halo(char* lds_halo, const HaloGeom<SPATIA
                 const int hp = (t >> 2) + 64 * (i0 + j);
                 if (i0 + j < kMaxHaloIter && hp < npix_halo)
                     *reinterpret_cast<decltype(vals[j].v)*>(
-                        lds_halo + (ROWB == 64 ? lds_off(hp, chunk) : lds_off128(hp, sub, chunk))) = vals[j].v;
+                        lds_halo + (ROWB == 64 ? halo_off(hp, chunk) : lds_off128(hp, sub, chunk))) = vals[j].v;
             }
             if (BATCH < kMaxHaloIter) __builtin_amdgcn_sched_barrier(0);
         }

@@ -10,6 +10,8 @@
 // 9 x BN x 64 B weight image are staged in LDS once and re-used by all 9 taps (LDS-tiled direct conv on
 // MFMA).  D = W(BN x K) * X(K x pixels): the accumulator has a pixel per lane and 4 consecutive output
 // channels per register quad, so NHWC stores are 8/16-byte pieces.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 template <typename T> struct Mma;
@@ -30,45 +32,88 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BN, int SPATIAL, int KS>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(const ConvParams p) {
+// Register-resident prefetch of the next work item's operands (global loads stay in flight while the
+// current item's MFMAs run).
+template <typename T, int NW>
+struct Prefetch {
+    Vec16<T> w[NW];                 // slice of the weight image (streamed mode)
+    Vec16<T> h[kMaxHaloIter];       // raw halo vectors (SP_NONE + concat only)
+    float sc[Vec16<T>::N], sh[Vec16<T>::N];
+    int mask, mode;
+};
+
+constexpr int kFwdThreads = 512;    // two 4-wave halves working in antiphase
+constexpr int kLoaderBlend = 3;     // template-only loader kind: sigmoid(alpha)-blend of two sources
+
+// Work decomposition: a persistent 8-wave workgroup owns one cout block (BN channels) and a contiguous range
+// of 256-pixel tiles.  Its two halves (waves 0-3 / 4-7) each walk their own tiles; a work item is (tile, cin
+// chunk of 64 B).  In every tick one half runs the MFMAs of its current item (and issues the global loads of
+// its next one) while the other half does the VALU work: epilogue of a finished tile, GroupNorm+LeakyReLU
+// transform and LDS commit of its next item.  The workgroup barrier at the end of a tick swaps the roles, so
+// each SIMD always has one matrix wave and one vector wave.
+template <typename T, int BN, int SPATIAL, int KS, bool WS, int EPI>
+__global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams p = pin_params(p_in);
     constexpr int NTAPS = KS * KS;
     constexpr int PAD = KS / 2;
     constexpr int NF = BN / 32;               // cout fragments per wave
     constexpr int VEC = Vec16<T>::N;
+    constexpr int WIMG_VECS = NTAPS * BN * 4; // 16-B vectors in one (cout block, cin chunk) weight image
+    constexpr int NW = WS ? 1 : (WIMG_VECS + kConvThreads - 1) / kConvThreads;
     typedef typename Mma<T>::frag frag_t;
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = threadIdx.x >> 8;        // wave-uniform
+    const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int TW = 1 << p.tw_log2, TH = p.th;
     const int hw = TW + 2 * PAD, hh = TH + 2 * PAD;
     const int npix_halo = hw * hh;
-    char* lds_halo = smem;
-    char* lds_w = smem + npix_halo * kRowBytes;
+    const int halo_bytes = npix_halo * kHaloRowBytes;
+    char* lds_halo = smem + half * halo_bytes;
+    char* lds_w = smem + 2 * halo_bytes + (WS ? 0 : half * (WIMG_VECS * 16));
 
-    // block -> (image, tile, cout block); cout block fastest so neighbours share the input tile
-    int bid = blockIdx.x;
-    const int cb = bid % p.ncb; bid /= p.ncb;
-    const int tx = bid % p.tiles_x; bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
-    const int n = bid / p.tiles_y;
-    const int ty0 = ty * TH, tx0 = tx * TW, bn0 = cb * BN;
-
-    HaloGeom<SPATIAL> geom;
-#pragma unroll
-    for (int i = 0; i < kMaxHaloIter; ++i)
-        halo_geom_init<SPATIAL>(geom, i, (t >> 2) + 64 * i, npix_halo, hw, PAD, n, ty0, tx0, p);
+    // this workgroup: one cout block, tiles [bt0, bt1); this half: [tile0, tile1)
+    const int cb = blockIdx.x % p.ncb;
+    const int bt0 = (blockIdx.x / p.ncb) * p.tiles_per_block;
+    const int bt1 = min(bt0 + p.tiles_per_block, p.ntiles);
+    const int nbt = bt1 - bt0, nh0 = (nbt + 1) >> 1;
+    const int tile0 = half ? bt0 + nh0 : bt0;
+    const int tile1 = half ? bt1 : bt0 + nh0;
+    const int nitems = (tile1 - tile0) * p.nchunks;              // this half
+    const int nticks = 2 * nh0 * p.nchunks + 2;                  // workgroup-uniform
+    const int bn0 = cb * BN;
+    const char* wbase = (const char*)p.wpacked + (size_t)cb * p.nchunks * (WIMG_VECS * 16);
+    // the halo is prefetched through registers only for the plain loader; gathers (pool / bilinear / blend)
+    // are staged synchronously in the commit phase
+    // (SPATIAL == kLoaderBlend: the two-source alpha blend, geometry of SP_NONE)
+    constexpr bool pf_halo = (SPATIAL == MRISR_SP_NONE);
+    constexpr int GSP = (SPATIAL == kLoaderBlend) ? MRISR_SP_NONE : SPATIAL;     // geometry / gather kind
 
     float blend_a = 0.f;
     if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
 
-    // per-lane halo row of its two pixels (tap (0,0))
-    int hp0[2];
+    if constexpr (WS) {   // weights-stationary: every cin chunk's image is loaded once, by all 512 threads
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase);
+        for (int v = threadIdx.x; v < p.nchunks * WIMG_VECS; v += kFwdThreads) reinterpret_cast<u32x4*>(lds_w)[v] = wsrc[v];
+    }
+
+    // per-lane LDS byte offsets of its two pixels' halo rows (tap (0,0), k-step 0) and of its weight row
+    int xb[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int pl = wave * 64 + mi * 32 + lr;
-        hp0[mi] = (pl >> p.tw_log2) * hw + (pl & (TW - 1));
+        xb[mi] = halo_off((pl >> p.tw_log2) * hw + (pl & (TW - 1)), lh);
+    }
+    int wb = lds_off(lr, lh);     // k-step 1 = this XOR 32; taps / fragments are constant offsets
+
+    // tile-independent halo slot coordinates of this thread: slot i = halo pixel (t>>2) + 64 i
+    int hyx[kMaxHaloIter];
+#pragma unroll
+    for (int i = 0; i < kMaxHaloIter; ++i) {
+        const int hp = (t >> 2) + 64 * i;
+        const int hy = hp / hw;
+        hyx[i] = hp < npix_halo ? ((hy << 16) | (hp - hy * hw)) : -1;
     }
 
     f32x16 acc[NF][2];
@@ -79,127 +124,224 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(const ConvP
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-    constexpr int WIMG_VECS = NTAPS * BN * 4;          // 16-B vectors in one weight image
-    const char* wbase = (const char*)p.wpacked + (size_t)cb * p.nchunks * (WIMG_VECS * 16);
+    // GroupNorm partial statistics, kept per lane across the tiles of one image (host guarantees that a
+    // group spans a multiple of 4 channels whenever p.stats is set)
+    const int gs = p.groups > 0 ? p.Cout / p.groups : 4;
+    float st_s[NF][4], st_ss[NF][4];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { st_s[ni][q] = 0.f; st_ss[ni][q] = 0.f; }
 
-    for (int kc = 0; kc < p.nchunks; ++kc) {
-        // ---- stage: weights image (already in LDS order, swizzled by the packer) + transformed halo
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase + (size_t)kc * (WIMG_VECS * 16));
-#pragma unroll
-        for (int j = 0; j < (WIMG_VECS + kConvThreads - 1) / kConvThreads; ++j) {
-            const int v = t + j * kConvThreads;
-            if (v < WIMG_VECS) reinterpret_cast<u32x4*>(lds_w)[v] = wsrc[v];
-        }
-        stage_halo<T, SPATIAL>(lds_halo, geom, kc, n, npix_halo, blend_a, p);
-        __syncthreads();
+    HaloGeom<GSP> geom;
+    Prefetch<T, NW> pf;
+    pf.mask = 0;
+    pf.mode = 0;
 
-        // ---- compute: 9 taps x 2 k-steps, operands straight from LDS
+    auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
+        const int tx = tile % p.tiles_x;
+        const int r = tile / p.tiles_x;
+        n = r / p.tiles_y;
+        ty0 = (r - n * p.tiles_y) * TH;
+        tx0 = tx * TW;
+    };
+    auto set_geom = [&](int n, int ty0, int tx0) {
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int tapoff = (tap / KS) * hw + (tap % KS);
+        for (int i = 0; i < kMaxHaloIter; ++i)
+            halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
+    };
+    // issue the global loads of a work item (geometry in `geom`, image n, cin chunk kc)
+    auto issue = [&](int n, int kc) {
+        if (p.dbg & 4) return;
+        if constexpr (!WS) {
+            const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase + (size_t)kc * (WIMG_VECS * 16));
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                frag_t xf[2], wf[NF];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    xf[mi] = *reinterpret_cast<const frag_t*>(lds_halo + lds_off(hp0[mi] + tapoff, 2 * ks + lh));
-#pragma unroll
-                for (int ni = 0; ni < NF; ++ni)
-                    wf[ni] = *reinterpret_cast<const frag_t*>(lds_w + lds_off(tap * BN + ni * 32 + lr, 2 * ks + lh));
-#pragma unroll
-                for (int ni = 0; ni < NF; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+            for (int j = 0; j < NW; ++j) {
+                const int v = t + j * kConvThreads;
+                if (v < WIMG_VECS) pf.w[j].v = *reinterpret_cast<const decltype(pf.w[j].v)*>(wsrc + v);
             }
         }
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias, (relu), store NHWC / pixel-shuffled, GroupNorm partial statistics
-    const int gs = p.groups > 0 ? p.Cout / p.groups : 1;        // channels per group
-    const int g_first = bn0 / gs;
-    float* lds_stats = reinterpret_cast<float*>(smem);          // [ngl][2]
-    const int ngl = p.groups > 0 ? ((min(bn0 + BN, p.Cout) - 1) / gs - g_first + 1) : 0;
-    if (p.stats) {
-        for (int i = t; i < 2 * ngl; i += kConvThreads) lds_stats[i] = 0.f;
-        __syncthreads();
-    }
-    T* outp = (T*)p.out;
+        if constexpr (pf_halo) {
+            {
+                const int c0 = kc * (kRowBytes / (int)sizeof(T)) + (t & 3) * VEC;
+                int which = 0, cs = c0;
+                if (p.nsrc > 1 && c0 >= p.src[0].C) { which = 1; cs = c0 - p.src[0].C; }
+                if (cs >= p.src[which].C) cs = -1;
+                load_affine<VEC>(p.src[which], n, cs, pf.sc, pf.sh);
+                pf.mode = p.src[which].mode;
+                const T* base = (const T*)p.src[which].ptr;
+                int mask = 0;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int pl = wave * 64 + mi * 32 + lr;
-        const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
-        const bool pv = oy < p.H && ox < p.W;
+                for (int i = 0; i < kMaxHaloIter; ++i) {
+                    const int o = which ? geom.off1[i] : geom.off0[i];
+                    if (o >= 0 && cs >= 0) {
+                        pf.h[i] = load_vec16(base + o + cs);
+                        mask |= 1 << i;
+                    } else {
+                        pf.h[i].zero();
+                    }
+                }
+                pf.mask = mask;
+            }
+        }
+    };
+    // transform + store the prefetched item into LDS (gather modes: stage synchronously)
+    auto commit = [&](int n, int kc) {
+        if (p.dbg & 2) return;
+        if constexpr (!WS) {
 #pragma unroll
-        for (int ni = 0; ni < NF; ++ni) {
+            for (int j = 0; j < NW; ++j) {
+                const int v = t + j * kConvThreads;
+                if (v < WIMG_VECS) *reinterpret_cast<decltype(pf.w[j].v)*>(lds_w + (size_t)v * 16) = pf.w[j].v;
+            }
+        }
+        if constexpr (pf_halo) {
+#pragma unroll
+            for (int i = 0; i < kMaxHaloIter; ++i) {
+                Vec16<T> v = pf.h[i];
+                if ((pf.mask >> i) & 1) transform_vec(v, pf.mode, pf.sc, pf.sh);
+                if (hyx[i] >= 0) *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
+            }
+        } else {
+            stage_halo<T, GSP>(lds_halo, geom, kc, n, npix_halo, blend_a, p, 0, t);
+        }
+    };
+    auto flush_stats = [&](int n) {
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int co = bn0 + ni * 32 + 8 * q + 4 * lh;      // first of 4 consecutive couts
-                float v[4];
-                float s = 0.f, ss = 0.f;
-                float sj[4], ssj[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a = acc[ni][mi][4 * q + j];
-                    if (p.bias && co + j < p.Cout) a += p.bias[co + j];
-                    if (p.relu_out) a = fmaxf(a, 0.f);
-                    a = to_f32(from_f32<T>(a));                   // statistics of what is stored
-                    v[j] = a;
-                    const bool ok = pv && (co + j < p.Cout);
-                    sj[j] = ok ? a : 0.f;
-                    ssj[j] = ok ? a * a : 0.f;
-                    s += sj[j];
-                    ss += ssj[j];
+                const int co = bn0 + ni * 32 + 8 * q + 4 * lh;
+                const float s = half_wave_sum(st_s[ni][q]), ss = half_wave_sum(st_ss[ni][q]);
+                if (lr == 0 && co < p.Cout) {
+                    const int g = co / gs;
+                    atomic_add_f64(&p.stats[((size_t)n * p.groups + g) * 2], (double)s);
+                    atomic_add_f64(&p.stats[((size_t)n * p.groups + g) * 2 + 1], (double)ss);
                 }
-                if (pv && co < p.Cout) {
-                    if (p.out_mode == MRISR_OUT_PLAIN) {
-                        T* dst = outp + ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + co;
-                        if (co + 3 < p.Cout) {
-                            if constexpr (sizeof(T) == 2) {
-                                bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                                *reinterpret_cast<bf16x4*>(dst) = pk;
-                            } else {
-                                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                            }
-                        } else {
-                            for (int j = 0; j < 4 && co + j < p.Cout; ++j) dst[j] = from_f32<T>(v[j]);
-                        }
-                    } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
-                        const int C4 = p.Cout >> 2, c4 = co >> 2;
+                st_s[ni][q] = 0.f;
+                st_ss[ni][q] = 0.f;
+            }
+    };
+    // epilogue of a finished tile: bias, (relu), NHWC / pixel-shuffled store, per-lane GroupNorm partial sums
+    auto epilogue = [&](int n, int ty0, int tx0) {
+        T* outp = (T*)p.out;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            outp[((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4] =
-                                from_f32<T>(v[j]);
+        for (int mi = 0; mi < 2; ++mi) {
+            const int pl = wave * 64 + mi * 32 + lr;
+            const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
+            const bool pv = oy < p.H && ox < p.W;
+            const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = bn0 + ni * 32 + 8 * q + 4 * lh;      // first of 4 consecutive couts
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[ni][mi][4 * q + j];
+                        acc[ni][mi][4 * q + j] = 0.f;
                     }
-                }
-                if (p.stats) {
-                    if ((gs & 3) == 0) {   // the 4 channels share a group
-                        s = half_wave_sum(s);
-                        ss = half_wave_sum(ss);
-                        if (lr == 0 && co < p.Cout) {
-                            const int gl = co / gs - g_first;
-                            atomicAdd(&lds_stats[2 * gl], s);
-                            atomicAdd(&lds_stats[2 * gl + 1], ss);
+                    if (pv && co < p.Cout) {
+                        if (p.bias) {
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + co);
+                            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
                         }
-                    } else {
+                        if (p.relu_out) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float a = half_wave_sum(sj[j]), b = half_wave_sum(ssj[j]);
-                            if (lr == 0 && co + j < p.Cout) {
-                                const int gl = (co + j) / gs - g_first;
-                                atomicAdd(&lds_stats[2 * gl], a);
-                                atomicAdd(&lds_stats[2 * gl + 1], b);
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        }
+                        st_s[ni][q] += (v[0] + v[1]) + (v[2] + v[3]);
+                        st_ss[ni][q] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        if (!(p.dbg & 1)) {
+                            if constexpr (EPI == MRISR_OUT_PLAIN) {
+                                T* dst = outp + pix * p.Cout + co;
+                                if constexpr (sizeof(T) == 2) {
+                                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                                    *reinterpret_cast<bf16x4*>(dst) = pk;
+                                } else {
+                                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                                }
+                            } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
+                                const int C4 = p.Cout >> 2, c4 = co >> 2;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    outp[((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4] =
+                                        from_f32<T>(v[j]);
                             }
                         }
                     }
                 }
             }
         }
+    };
+
+    // ---- schedule: commit phase c at tick 2c + half, MFMA phase c at tick 2c + 1 + half
+    int cur_tile = tile0, cur_kc = 0, cur_n = 0, cur_ty0 = 0, cur_tx0 = 0;       // item c
+    int nxt_tile = tile0, nxt_kc = 0, nxt_n = 0, nxt_ty0 = 0, nxt_tx0 = 0;       // item c + 1
+    int ep_n = 0, ep_ty0 = 0, ep_tx0 = 0;
+    bool ep_pending = false;
+    if (nitems > 0) {
+        decode(cur_tile, cur_n, cur_ty0, cur_tx0);
+        set_geom(cur_n, cur_ty0, cur_tx0);
+        issue(cur_n, 0);
     }
-    if (p.stats) {
+    for (int tick = 0; tick < nticks; ++tick) {
+        const int phase = tick - half;
+        const int c = phase >> 1;
+        if (phase >= 0 && (phase & 1) == 0) {
+            // ------------------------------------------------ vector phase
+            if (ep_pending) {
+                epilogue(ep_n, ep_ty0, ep_tx0);
+                if (p.stats && (c >= nitems || cur_n != ep_n)) flush_stats(ep_n);
+                ep_pending = false;
+            }
+            if (c < nitems) {
+                commit(cur_n, cur_kc);
+                nxt_tile = cur_tile; nxt_kc = cur_kc + 1; nxt_n = cur_n; nxt_ty0 = cur_ty0; nxt_tx0 = cur_tx0;
+                if (nxt_kc == p.nchunks) {
+                    nxt_kc = 0;
+                    nxt_tile = cur_tile + 1;
+                    if (nxt_tile < tile1) {
+                        decode(nxt_tile, nxt_n, nxt_ty0, nxt_tx0);
+                        set_geom(nxt_n, nxt_ty0, nxt_tx0);
+                    }
+                }
+            }
+        } else if (phase >= 0 && c < nitems) {
+            // ------------------------------------------------ matrix phase
+            if (c + 1 < nitems) issue(nxt_n, nxt_kc);
+            const char* wl = lds_w + (WS ? (size_t)cur_kc * (WIMG_VECS * 16) : 0);
+            // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
+            // out of the persistent loop into 36 VGPRs
+            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
+            if (!(p.dbg & 8)) {
+#pragma unroll
+                for (int tap = 0; tap < NTAPS; ++tap) {
+                    const int tapoff = ((tap / KS) * hw + (tap % KS)) * kHaloRowBytes;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        frag_t xf[2], wf[NF];
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            xf[mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni)
+                            wf[ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+                    }
+                }
+            }
+            if (cur_kc == p.nchunks - 1) {
+                ep_pending = true;
+                ep_n = cur_n; ep_ty0 = cur_ty0; ep_tx0 = cur_tx0;
+            }
+            cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
+        }
         __syncthreads();
-        for (int i = t; i < 2 * ngl; i += kConvThreads)
-            atomic_add_f64(&p.stats[((size_t)n * p.groups + g_first) * 2 + i], (double)lds_stats[i]);
     }
 }
 
@@ -304,29 +446,82 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
     p.ncb = ceil_div(d->Cout, BN); p.CoutP = p.ncb * BN;
     p.nsrc = d->nsrc; p.combine = d->combine; p.out_mode = d->out_mode; p.groups = d->stats ? d->groups : 0;
     p.relu_out = d->relu_out;
+    { const char* e = getenv("MRISR_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     conv_choose_tile(d->W, p.th, p.tw_log2);
     p.tiles_x = ceil_div(d->W, 1 << p.tw_log2); p.tiles_y = ceil_div(d->H, p.th);
     return MRISR_OK;
 }
 
+static int g_num_cus = 0;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s);
+
 template <typename T, int BN, int SPATIAL, int KS>
-static int launch_conv(const ConvParams& p, hipStream_t s) {
+static int launch_conv(ConvParams& p, hipStream_t s) {
     const int TW = 1 << p.tw_log2, pad = KS / 2;
-    const size_t lds = (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * kRowBytes + (size_t)KS * KS * BN * kRowBytes;
-    const int grid = p.N * p.tiles_y * p.tiles_x * p.ncb;
-    auto kern = conv_igemm_kernel<T, BN, SPATIAL, KS>;
+    const size_t halo_bytes = (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * kHaloRowBytes;
+    const size_t wimg = (size_t)KS * KS * BN * kRowBytes;
+    // weights-stationary when every cin chunk fits next to the two halo tiles
+    p.ws = (p.nchunks * wimg + 2 * halo_bytes <= 150 * 1024) ? 1 : 0;
+    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg;
+    p.ntiles = p.N * p.tiles_y * p.tiles_x;
+    int per_cb = num_cus() / p.ncb;                     // persistent workgroups per cout block, one per CU
+    if (per_cb < 1) per_cb = 1;
+    const int pairs = ceil_div(p.ntiles, 2);
+    if (per_cb > pairs) per_cb = pairs;
+    p.tiles_per_block = ceil_div(p.ntiles, per_cb);
+    per_cb = ceil_div(p.ntiles, p.tiles_per_block);
+    const int grid = per_cb * p.ncb;
+    // tiny channel counts (a GroupNorm group narrower than 4 channels): statistics by a separate pass
+    double* stats = p.stats;
+    const bool stats_sep = stats && ((p.Cout / p.groups) & 3);
+    if (stats_sep) p.stats = nullptr;
+    constexpr bool kPS = (SPATIAL == MRISR_SP_NONE && KS == 3);   // pixel-shuffle epilogue: plain 3x3 convs only
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (kPS) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kConvThreads), lds, s, p);
+    if (p.out_mode == MRISR_OUT_PIXEL_SHUFFLE2) {
+        if constexpr (kPS) {
+            if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+        } else {
+            MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: pixel-shuffle epilogue needs a 3x3 conv with a plain source");
+        }
+    } else if (p.ws) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+    }
     MRISR_CHECK_LAUNCH("conv_forward");
+    if (stats_sep) {
+        const bool ps = p.out_mode == MRISR_OUT_PIXEL_SHUFFLE2;
+        return launch_gn_stats(TypeTraits<T>::kDtype, p.out, stats, p.N, (ps ? 4 : 1) * p.H * p.W, ps ? p.Cout / 4 : p.Cout, p.groups, s);
+    }
     return MRISR_OK;
 }
 
 template <typename T, int BN>
-static int dispatch_conv_sp(const ConvParams& p, int spatial, int ks, hipStream_t s) {
+static int dispatch_conv_sp(ConvParams& p, int spatial, int ks, hipStream_t s) {
+    if (p.combine == MRISR_COMBINE_BLEND) {
+        if (ks != 3) MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: blend needs a 3x3 conv");
+        return launch_conv<T, BN, kLoaderBlend, 3>(p, s);
+    }
     if (ks == 3) {
         if (spatial == MRISR_SP_NONE) return launch_conv<T, BN, MRISR_SP_NONE, 3>(p, s);
         if (spatial == MRISR_SP_POOL2) return launch_conv<T, BN, MRISR_SP_POOL2, 3>(p, s);

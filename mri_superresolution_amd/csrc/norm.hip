@@ -439,3 +439,213 @@ extern "C" int mrisr_channel_sum(int dtype, const void* x, float* out, size_t np
     MRISR_CHECK_LAUNCH("channel_sum");
     return MRISR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone GroupNorm statistics of an NHWC tensor: stats[n][g] += (sum, sum of squares).  Used by
+// conv_forward only when a group has fewer than 4 channels (tiny test networks); otherwise the
+// statistics come out of the convolution epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int HW,
+                                                       int C, int groups, int pix_per_block) {
+    __shared__ float lds[64 * 2];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int gs = C / groups;
+    for (int i = t; i < groups * 2; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    const T* xb = x + (size_t)n * HW * C;
+    const int ppb = 256 / C, c = t % C, pl = t / C;       // C <= 256: one channel per thread column
+    if (pl < ppb) {
+        float s = 0.f, ss = 0.f;
+        for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+            const float v = to_f32(xb[(size_t)pix * C + c]);
+            s += v;
+            ss += v * v;
+        }
+        atomicAdd(&lds[2 * (c / gs)], s);
+        atomicAdd(&lds[2 * (c / gs) + 1], ss);
+    }
+    __syncthreads();
+    for (int i = t; i < groups * 2; i += 256) atomic_add_f64(&stats[(size_t)n * groups * 2 + i], (double)lds[i]);
+}
+
+int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s) {
+    if (groups > 64 || C > 256) MRISR_FAIL(MRISR_E_UNSUPPORTED, "gn_stats: C %d groups %d", C, groups);
+    const int ppblk = 1024;
+    dim3 grid(ceil_div(HW, ppblk), N);
+    if (dtype == MRISR_BF16) gn_stats_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, stats, HW, C, groups, ppblk);
+    else gn_stats_kernel<float><<<grid, 256, 0, s>>>((const float*)x, stats, HW, C, groups, ppblk);
+    MRISR_CHECK_LAUNCH("gn_stats");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[n][y][x][c] = max over the 2x2 window of LeakyReLU(x*scale+shift)   (MaxPool2d(2) of the activated tensor,
+// unet_model.py:52; floor semantics).  Materialises the (4x smaller) pooled activation so that the encoder
+// convolutions and their weight gradients run on the plain prefetching loader.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_pool2_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, T* __restrict__ out, int N,
+                                                         int H, int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = C / VEC, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * nvec;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        size_t r = idx / nvec;
+        const int xo = r % Wo; r /= Wo;
+        const int yo = r % Ho;
+        const int n = r / Ho;
+        const int c = cv * VEC;
+        float sc[VEC], sh[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
+        const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
+        const Vec16<T> v00 = load_vec16(b), v01 = load_vec16(b + C), v10 = load_vec16(b + (size_t)W * C), v11 = load_vec16(b + (size_t)W * C + C);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float a = lrelu(v00.get(e) * sc[e] + sh[e]), bq = lrelu(v01.get(e) * sc[e] + sh[e]);
+            const float cq = lrelu(v10.get(e) * sc[e] + sh[e]), d = lrelu(v11.get(e) * sc[e] + sh[e]);
+            o.set(e, fmaxf(fmaxf(a, bq), fmaxf(cq, d)));
+        }
+        store_vec16(out + idx * VEC, o);
+    }
+}
+
+extern "C" int mrisr_norm_pool2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
+                                int H, int W, int C, void* stream) {
+    if (!x || !scale || !shift || !out) MRISR_FAIL(MRISR_E_ARG, "norm_pool2: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec || H < 2 || W < 2) MRISR_FAIL(MRISR_E_SHAPE, "norm_pool2: C %d H %d W %d", C, H, W);
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == MRISR_BF16) norm_pool2_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, H, W, C);
+    else if (dtype == MRISR_F32) norm_pool2_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, H, W, C);
+    else MRISR_FAIL(MRISR_E_DTYPE, "norm_pool2: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("norm_pool2");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear x2 (align_corners=True) of a raw tensor z_low [N][h][w][C] -> z [N][2h][2w][C] plus the GroupNorm
+// statistics of z.  The decoder's "Upsample -> conv1x1" (unet_model.py:71-72) is evaluated as
+// "conv1x1 -> Upsample" (both are linear; identical up to fp rounding, 4x fewer conv FLOPs).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_stats_kernel(const T* __restrict__ zl, T* __restrict__ z,
+                                                              double* __restrict__ stats, int h, int w, int C,
+                                                              int groups, int pix_per_block) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float lds[64 * 2];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    const int H = 2 * h, W = 2 * w, HW = H * W;
+    const int gs = C / groups;
+    for (int i = t; i < groups * 2; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    float s[VEC], ss[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    const T* zb = zl + (size_t)n * h * w * C + c;
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    if (pl < ppb)
+        for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+            const int y = pix / W, x = pix - y * W;
+            int y0, y1, x0, x1;
+            float wy, wx;
+            up2_coord(y, h, y0, y1, wy);
+            up2_coord(x, w, x0, x1, wx);
+            const Vec16<T> v00 = load_vec16(zb + ((size_t)y0 * w + x0) * C), v01 = load_vec16(zb + ((size_t)y0 * w + x1) * C);
+            const Vec16<T> v10 = load_vec16(zb + ((size_t)y1 * w + x0) * C), v11 = load_vec16(zb + ((size_t)y1 * w + x1) * C);
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float a = (1.f - wy) * ((1.f - wx) * v00.get(e) + wx * v01.get(e)) +
+                                wy * ((1.f - wx) * v10.get(e) + wx * v11.get(e));
+                o.set(e, a);
+                s[e] += a;
+                ss[e] += a * a;
+            }
+            store_vec16(z + ((size_t)n * HW + pix) * C + c, o);
+        }
+    if (stats) {
+        if (pl < ppb) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                atomicAdd(&lds[2 * ((c + e) / gs)], s[e]);
+                atomicAdd(&lds[2 * ((c + e) / gs) + 1], ss[e]);
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < groups * 2; i += 256) atomic_add_f64(&stats[(size_t)n * groups * 2 + i], (double)lds[i]);
+    }
+}
+
+extern "C" int mrisr_upsample2_stats(int dtype, const void* z_low, void* z, double* stats, int N, int h, int w, int C,
+                                     int groups, void* stream) {
+    if (!z_low || !z) MRISR_FAIL(MRISR_E_ARG, "upsample2_stats: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec || C / vec > 256 || groups <= 0 || groups > 64 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "upsample2_stats: C %d groups %d", C, groups);
+    const int ppb = 256 / (C / vec);
+    const int ppblk = ppb * 16;
+    dim3 grid(ceil_div(4 * h * w, ppblk), N);
+    if (dtype == MRISR_BF16) upsample2_stats_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)z_low, (bf16_t*)z, stats, h, w, C, groups, ppblk);
+    else if (dtype == MRISR_F32) upsample2_stats_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)z_low, (float*)z, stats, h, w, C, groups, ppblk);
+    else MRISR_FAIL(MRISR_E_DTYPE, "upsample2_stats: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("upsample2_stats");
+    return MRISR_OK;
+}
+
+// adjoint: dz [N][2h][2w][C] -> dz_low [N][h][w][C]
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restrict__ dz, T* __restrict__ dzl, int N,
+                                                                int h, int w, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = C / VEC;
+    const size_t total = (size_t)N * h * w * nvec;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        size_t r = idx / nvec;
+        const int x = r % w; r /= w;
+        const int y = r % h;
+        const int n = r / h;
+        int iy[6], ix[6];
+        float wy[6], wx[6];
+        up2_adjoint_weights(y, h, iy, wy);
+        up2_adjoint_weights(x, w, ix, wx);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        const T* b = dz + (size_t)n * 4 * h * w * C + cv * VEC;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            if (wy[a] == 0.f) continue;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (wx[q] == 0.f) continue;
+                const Vec16<T> d = load_vec16(b + ((size_t)iy[a] * (2 * w) + ix[q]) * C);
+                const float wv = wy[a] * wx[q];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += wv * d.get(e);
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+        store_vec16(dzl + idx * VEC, o);
+    }
+}
+
+extern "C" int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, int N, int h, int w, int C, void* stream) {
+    if (!dz || !dz_low) MRISR_FAIL(MRISR_E_ARG, "upsample2_adjoint: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "upsample2_adjoint: C %d", C);
+    const size_t total = (size_t)N * h * w * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == MRISR_BF16) upsample2_adjoint_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)dz, (bf16_t*)dz_low, N, h, w, C);
+    else if (dtype == MRISR_F32) upsample2_adjoint_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)dz_low, N, h, w, C);
+    else MRISR_FAIL(MRISR_E_DTYPE, "upsample2_adjoint: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("upsample2_adjoint");
+    return MRISR_OK;
+}

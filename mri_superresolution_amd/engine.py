@@ -67,10 +67,13 @@ class Layer:
     combine: int = L.COMBINE_CONCAT
     bias: bool = False
     out_mode: int = L.OUT_PLAIN
-    # per-forward geometry
+    pool_src: bool = False      # source = materialised MaxPool2d(2) of the activated source node (encoder)
+    post_up: bool = False       # 1x1 conv evaluated at low resolution, bilinear x2 applied to its output
+    # per-forward geometry / saved tensors
     H: int = 0
     W: int = 0
     offs: list = field(default_factory=list)
+    aux: Optional[torch.Tensor] = None
 
 
 class KernelTimer:
@@ -131,9 +134,9 @@ class UNetEngine:
             self.nodes[name] = n
             return n
 
-        def dconv(prefix, src: List[Source], cin, cout, combine=L.COMBINE_CONCAT):
+        def dconv(prefix, src: List[Source], cin, cout, combine=L.COMBINE_CONCAT, pool_src=False):
             a = node(f"{prefix}.double_conv.0", cout, f"{prefix}.double_conv.1.weight", f"{prefix}.double_conv.1.bias")
-            self.layers.append(Layer(f"{prefix}.double_conv.0", cin, cout, 3, src, a, combine))
+            self.layers.append(Layer(f"{prefix}.double_conv.0", cin, cout, 3, src, a, combine, pool_src=pool_src))
             b = node(f"{prefix}.double_conv.3", cout, f"{prefix}.double_conv.4.weight", f"{prefix}.double_conv.4.bias")
             self.layers.append(Layer(f"{prefix}.double_conv.3", cout, cout, 3, [Source(a)], b))
             return b
@@ -142,14 +145,16 @@ class UNetEngine:
         self.stem = node("inc.double_conv.0", f, "inc.double_conv.1.weight", "inc.double_conv.1.bias")
         x1 = node("inc.double_conv.3", f, "inc.double_conv.4.weight", "inc.double_conv.4.bias")
         self.layers.append(Layer("inc.double_conv.3", f, f, 3, [Source(self.stem)], x1))
-        x2 = dconv("down1.maxpool_conv.1", [Source(x1, L.SP_POOL2)], f, 2 * f)
-        x3 = dconv("down2.maxpool_conv.1", [Source(x2, L.SP_POOL2)], 2 * f, 4 * f)
-        x4 = dconv("down3.maxpool_conv.1", [Source(x3, L.SP_POOL2)], 4 * f, 8 * f)
+        x2 = dconv("down1.maxpool_conv.1", [Source(x1)], f, 2 * f, pool_src=True)
+        x3 = dconv("down2.maxpool_conv.1", [Source(x2)], 2 * f, 4 * f, pool_src=True)
+        x4 = dconv("down3.maxpool_conv.1", [Source(x3)], 4 * f, 8 * f, pool_src=True)
         # decoder (unet_model.py:144-146, 70-94)
         u = x4
         for j, (skip, cout) in enumerate(((x3, 4 * f), (x2, 2 * f), (x1, f)), start=1):
             up = node(f"up{j}.up.1", cout, f"up{j}.up.2.weight", f"up{j}.up.2.bias")
-            self.layers.append(Layer(f"up{j}.up.1", 2 * cout, cout, 1, [Source(u, L.SP_UP2)], up))
+            # Upsample -> conv1x1 (unet_model.py:71-72) runs as conv1x1 at low resolution -> bilinear x2 (linear ops
+            # commute): 4x fewer conv FLOPs and no gather inside the conv loader
+            self.layers.append(Layer(f"up{j}.up.1", 2 * cout, cout, 1, [Source(u)], up, post_up=True))
             u = dconv(f"up{j}.conv", [Source(skip), Source(up)], 2 * cout, cout)
         # dual-branch head (unet_model.py:150-173)
         fb = node("final_up_bilinear.1", f // 2, "final_up_bilinear.2.weight", "final_up_bilinear.2.bias")
@@ -197,6 +202,11 @@ class UNetEngine:
         d.combine, d.out_mode, d.groups, d.relu_out = layer.combine, layer.out_mode, GN_GROUPS, 0
         for i, (s, (oy, ox)) in enumerate(zip(layer.srcs, layer.offs)):
             n = s.node
+            if layer.pool_src:          # materialised pooled activation: a plain tensor
+                d.src[i].ptr = layer.aux.data_ptr()
+                d.src[i].C, d.src[i].H, d.src[i].W = n.C, layer.H, layer.W
+                d.src[i].mode, d.src[i].spatial = L.SRC_RAW, L.SP_NONE
+                continue
             d.src[i].ptr = n.raw.data_ptr()
             d.src[i].scale = n.scale.data_ptr()
             d.src[i].shift = n.shift.data_ptr()
@@ -252,17 +262,23 @@ class UNetEngine:
         for layer in self.layers:
             # conv geometry: first source fixes the size (skip for concat); others are padded into it
             vh, vw = self._virtual_hw(layer.srcs[0])
+            if layer.pool_src:
+                sn = layer.srcs[0].node
+                vh, vw = sn.H // 2, sn.W // 2
+                layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
+                L.call("mrisr_norm_pool2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
+                       layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st)
             layer.H, layer.W = vh, vw
             layer.offs = []
             for sidx, src in enumerate(layer.srcs):
-                h, w = self._virtual_hw(src)
+                h, w = (vh, vw) if layer.pool_src else self._virtual_hw(src)
                 dy, dx = vh - h, vw - w
                 if dy < 0 or dx < 0:
                     raise RuntimeError(f"{layer.name}: source larger than the conv input")
                 layer.offs.append((dy // 2, dx // 2))        # F.pad split, unet_model.py:89-90
             o = layer.out
             o.N = N
-            if layer.out_mode == L.OUT_PIXEL_SHUFFLE2:
+            if layer.out_mode == L.OUT_PIXEL_SHUFFLE2 or layer.post_up:
                 o.H, o.W = 2 * vh, 2 * vw
             else:
                 o.H, o.W = vh, vw
@@ -271,10 +287,16 @@ class UNetEngine:
             # training: the optimiser rewrites the masters through raw pointers every step -> always repack
             d.wpacked = self._packed_weight(layer, params, dt, 0, st, force=training).data_ptr()
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
-            d.out = o.raw.data_ptr()
-            d.stats = o.stats.data_ptr()
+            if layer.post_up:
+                zlow = torch.empty((N, vh, vw, o.C), dtype=dtype, device=dev)
+                d.out, d.stats = zlow.data_ptr(), None
+            else:
+                d.out, d.stats = o.raw.data_ptr(), o.stats.data_ptr()
             self._launch("fwd", dt, N, vh, vw, layer.cin, layer.cout, layer.srcs[0].spatial, layer.ks,
                          lambda: L.call("mrisr_conv_forward", C.byref(d), st))
+            if layer.post_up:
+                L.call("mrisr_upsample2_stats", dt, zlow.data_ptr(), o.raw.data_ptr(), o.stats.data_ptr(),
+                       N, vh, vw, o.C, GN_GROUPS, st)
             finalize(o)
 
         hn = self.head_in
@@ -286,10 +308,12 @@ class UNetEngine:
         if training:
             ctx = {"x": x, "out": out, "dtype": dtype, "N": N, "arena": arena,
                    "nodes": {k: (n.N, n.H, n.W, n.raw, n.scale, n.shift, n.meanrstd) for k, n in self.nodes.items()},
-                   "layers": {l.name: (l.H, l.W, list(l.offs)) for l in self.layers}}
+                   "layers": {l.name: (l.H, l.W, list(l.offs), l.aux) for l in self.layers}}
         else:
             for n in nodes:
                 n.raw = n.scale = n.shift = n.meanrstd = n.stats = None
+        for l in self.layers:
+            l.aux = None
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -307,7 +331,7 @@ class UNetEngine:
             n.N, n.H, n.W, n.raw, n.scale, n.shift, n.meanrstd = ctx["nodes"][k]
             n.consumers = []
         for l in self.layers:
-            l.H, l.W, l.offs = ctx["layers"][l.name]
+            l.H, l.W, l.offs, l.aux = ctx["layers"][l.name]
         dout = dout.contiguous()
 
         def node_backward(n: Node) -> torch.Tensor:
@@ -354,6 +378,10 @@ class UNetEngine:
         for layer in reversed(self.layers):
             o = layer.out
             dy = node_backward(o)
+            if layer.post_up:       # adjoint of the bilinear x2 that follows the low-resolution 1x1 conv
+                dyl = torch.empty((N, layer.H, layer.W, layer.cout), dtype=dtype, device=dev)
+                L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st)
+                dy = dyl
             d = self._desc(layer, dt, N, params)
             self._launch("wgrad", dt, N, layer.H, layer.W, layer.cin, layer.cout, layer.srcs[0].spatial, layer.ks,
                          lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
@@ -384,7 +412,8 @@ class UNetEngine:
             else:
                 coff = 0
                 for src, (oy, ox) in zip(layer.srcs, layer.offs):
-                    src.node.consumers.append((dain, layer.cin, coff, layer.H, layer.W, src.spatial, oy, ox, 0))
+                    sp = L.SP_POOL2 if layer.pool_src else src.spatial
+                    src.node.consumers.append((dain, layer.cin, coff, layer.H, layer.W, sp, oy, ox, 0))
                     coff += src.node.C
             if bucket_hook:
                 bucket_hook(layer.name)
@@ -398,3 +427,5 @@ class UNetEngine:
         for n in self.nodes.values():
             n.raw = n.scale = n.shift = n.meanrstd = n.stats = None
             n.consumers = []
+        for l in self.layers:
+            l.aux = None

@@ -41,11 +41,13 @@ def test_conv3x3_raw(dt, shape):
     out, stats = U.conv_forward(dt, [U.SrcSpec(x)], wt, h, w, 3)
     ref = F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), padding=1)
     assert U.relerr(out, ref) <= TOL_OUT[dt]
-    # GroupNorm statistics of the stored tensor
+    # GroupNorm statistics (of the fp32 accumulators, i.e. of the un-rounded conv output)
     gs = cout // 8
-    o = out.view(n, 8, gs, h, w).double()
-    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-3 * o.abs().max().item())
-    assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    o = ref.view(n, 8, gs, h, w).double()
+    # (groups narrower than 4 channels take the stand-alone statistics pass over the STORED tensor: bf16 rounding)
+    loose = dt == L.BF16 and gs % 4 != 0
+    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=(3e-2 if loose else 1e-3) * o.abs().max().item())
+    assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=2e-3 if loose else 1e-4)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -103,7 +105,7 @@ def test_conv_pixel_shuffle_epilogue(dt):
     ref = F.pixel_shuffle(F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), b, padding=1), 2)
     assert out.shape == ref.shape == (n, cout // 4, 2 * h, 2 * w)
     assert U.relerr(out, ref) <= TOL_OUT[dt]
-    o = out.view(n, 8, cout // 32, 2 * h, 2 * w).double()
+    o = ref.view(n, 8, cout // 32, 2 * h, 2 * w).double()
     assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-3 * o.abs().max().item())
 
 
@@ -286,6 +288,33 @@ def test_blend_alpha_grad_and_channel_sum(dt):
     cs = torch.zeros(c, device=U.DEV)
     L.call("mrisr_channel_sum", dt, dev[0].data_ptr(), cs.data_ptr(), n * h * w, c, U.stream())
     assert U.relerr(cs.cpu(), U.rounded(da, dt).sum((0, 2, 3))) <= 1e-4
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_norm_pool2_and_upsample2(dt):
+    n, c, h, w = 2, 32, 11, 19
+    x = rnd(n, c, h, w, seed=85)
+    sc, sh = gn_affine(n, c, 86)
+    xd, scd, shd = U.nhwc(x, dt), sc.to(U.DEV), sh.to(U.DEV)
+    out = torch.empty((n, h // 2, w // 2, c), dtype=U.tdt(dt), device=U.DEV)
+    L.call("mrisr_norm_pool2", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), out.data_ptr(), n, h, w, c, U.stream())
+    ref = F.max_pool2d(F.leaky_relu(U.rounded(x, dt) * sc.view(n, c, 1, 1) + sh.view(n, c, 1, 1), 0.2), 2)
+    assert U.relerr(U.nchw(out), ref) <= TOL_OUT[dt]
+    # bilinear x2 + statistics, and its adjoint
+    z = torch.empty((n, 2 * h, 2 * w, c), dtype=U.tdt(dt), device=U.DEV)
+    stats = torch.zeros(n * 16, dtype=torch.float64, device=U.DEV)
+    L.call("mrisr_upsample2_stats", dt, xd.data_ptr(), z.data_ptr(), stats.data_ptr(), n, h, w, c, 8, U.stream())
+    xr = U.rounded(x, dt).requires_grad_(True)
+    up = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+    assert U.relerr(U.nchw(z), up.detach()) <= TOL_OUT[dt]
+    o = up.detach().view(n, 8, c // 8, 2 * h, 2 * w).double()
+    assert torch.allclose(stats.cpu().view(n, 8, 2)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    dz = rnd(n, c, 2 * h, 2 * w, seed=87)
+    up.backward(U.rounded(dz, dt))
+    dzd = U.nhwc(dz, dt)
+    dzl = torch.empty((n, h, w, c), dtype=U.tdt(dt), device=U.DEV)
+    L.call("mrisr_upsample2_adjoint", dt, dzd.data_ptr(), dzl.data_ptr(), n, h, w, c, U.stream())
+    assert U.relerr(U.nchw(dzl), xr.grad) <= TOL_OUT[dt]
 
 
 # ------------------------------------------------------------------------------------------- adam / cast
