@@ -111,6 +111,10 @@ int mrisr_gn_finalize(const double* stats, const float* gamma, const float* beta
  * activation, so the encoder convolutions read a plain tensor.                                            */
 int mrisr_norm_pool2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
                      int H, int W, int C, void* stream);
+/* out [N][2h][2w][C] = bilinear x2 (align_corners=True) of LeakyReLU(x*scale+shift): materialised input of
+ * final_up_bilinear's 3x3 conv (unet_model.py:151-152).                                                     */
+int mrisr_norm_upsample2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
+                         int h, int w, int C, void* stream);
 /* z [N][2h][2w][C] = bilinear x2 (align_corners=True) of z_low [N][h][w][C], plus GroupNorm statistics of z
  * (stats [N][groups][2] double, accumulated; may be NULL).  With mrisr_conv_forward on the low-resolution
  * tensor this evaluates nn.Upsample -> nn.Conv2d(1x1) (unet_model.py:71-72) as conv -> upsample.           */

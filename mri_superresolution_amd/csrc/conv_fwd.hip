@@ -34,11 +34,14 @@ template <> struct Mma<float> {
 
 // Register-resident prefetch of the next work item's operands (global loads stay in flight while the
 // current item's MFMAs run).
-template <typename T, int NW>
+// NH = raw vectors kept per halo slot: 1 plain / 2 blend (both sources) / 4 gathers (2x2 pool window or the
+// 4 bilinear taps) / 0 = no halo prefetch (staged synchronously in the vector phase).
+template <typename T, int NW, int NH>
 struct Prefetch {
-    Vec16<T> w[NW];                 // slice of the weight image (streamed mode)
-    Vec16<T> h[kMaxHaloIter];       // raw halo vectors (SP_NONE + concat only)
-    float sc[Vec16<T>::N], sh[Vec16<T>::N];
+    Vec16<T> w[NW];                               // slice of the weight image (streamed mode)
+    Vec16<T> h[kMaxHaloIter][NH > 0 ? NH : 1];    // raw halo vectors
+    float sc[Vec16<T>::N], sh[Vec16<T>::N];       // GroupNorm affine of the chunk's channels (source 0 / the only one)
+    float sc1[NH == 2 ? Vec16<T>::N : 1], sh1[NH == 2 ? Vec16<T>::N : 1];   // blend: source 1
     int mask, mode;
 };
 
@@ -87,8 +90,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // the halo is prefetched through registers only for the plain loader; gathers (pool / bilinear / blend)
     // are staged synchronously in the commit phase
     // (SPATIAL == kLoaderBlend: the two-source alpha blend, geometry of SP_NONE)
-    constexpr bool pf_halo = (SPATIAL == MRISR_SP_NONE);
     constexpr int GSP = (SPATIAL == kLoaderBlend) ? MRISR_SP_NONE : SPATIAL;     // geometry / gather kind
+    // halo prefetch through registers: plain 1 vector per slot, blend 2, gathers 4 (only where the accumulators
+    // leave room: BN = 32); otherwise the halo is staged synchronously in the vector phase
+    constexpr int NH = SPATIAL == MRISR_SP_NONE ? 1 : SPATIAL == kLoaderBlend ? 2 : (BN == 32 ? 4 : 0);
+    constexpr bool pf_halo = NH > 0;
 
     float blend_a = 0.f;
     if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         for (int q = 0; q < 4; ++q) { st_s[ni][q] = 0.f; st_ss[ni][q] = 0.f; }
 
     HaloGeom<GSP> geom;
-    Prefetch<T, NW> pf;
+    Prefetch<T, NW, NH> pf;
     pf.mask = 0;
     pf.mode = 0;
 
@@ -145,10 +151,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         ty0 = (r - n * p.tiles_y) * TH;
         tx0 = tx * TW;
     };
+    int upflags = 0;      // UP2 gather prefetch: bit 2i = second row differs, bit 2i+1 = second column differs
     auto set_geom = [&](int n, int ty0, int tx0) {
 #pragma unroll
         for (int i = 0; i < kMaxHaloIter; ++i)
             halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
+        if constexpr (NH == 4 && GSP == MRISR_SP_UP2) {
+            int f = 0;
+#pragma unroll
+            for (int i = 0; i < kMaxHaloIter; ++i) f |= ((geom.dyo[i] != 0) << (2 * i)) | ((geom.dxo[i] != 0) << (2 * i + 1));
+            upflags = f;
+        }
     };
     // issue the global loads of a work item (geometry in `geom`, image n, cin chunk kc)
     auto issue = [&](int n, int kc) {
@@ -162,31 +175,54 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
         }
         if constexpr (pf_halo) {
-            {
-                const int c0 = kc * (kRowBytes / (int)sizeof(T)) + (t & 3) * VEC;
-                int which = 0, cs = c0;
+            const int c0 = kc * (kRowBytes / (int)sizeof(T)) + (t & 3) * VEC;
+            int which = 0, cs = c0;
+            if constexpr (NH == 1) {
                 if (p.nsrc > 1 && c0 >= p.src[0].C) { which = 1; cs = c0 - p.src[0].C; }
-                if (cs >= p.src[which].C) cs = -1;
-                load_affine<VEC>(p.src[which], n, cs, pf.sc, pf.sh);
-                pf.mode = p.src[which].mode;
-                const T* base = (const T*)p.src[which].ptr;
-                int mask = 0;
+            }
+            if (cs >= p.src[which].C) cs = -1;
+            load_affine<VEC>(p.src[which], n, cs, pf.sc, pf.sh);
+            if constexpr (NH == 2) load_affine<VEC>(p.src[1], n, cs, pf.sc1, pf.sh1);
+            pf.mode = p.src[which].mode;
+            const T* base = (const T*)p.src[which].ptr;
+            int mask = 0;
 #pragma unroll
-                for (int i = 0; i < kMaxHaloIter; ++i) {
+            for (int i = 0; i < kMaxHaloIter; ++i) {
+                if constexpr (NH == 1) {
                     const int o = which ? geom.off1[i] : geom.off0[i];
+                    if (o >= 0 && cs >= 0) { pf.h[i][0] = load_vec16(base + o + cs); mask |= 1 << i; }
+                    else pf.h[i][0].zero();
+                } else if constexpr (NH == 2) {
+                    const int o0 = geom.off0[i], o1 = geom.off1[i];
+                    if (o0 >= 0 && o1 >= 0 && cs >= 0) {
+                        pf.h[i][0] = load_vec16(base + o0 + cs);
+                        pf.h[i][1] = load_vec16((const T*)p.src[1].ptr + o1 + cs);
+                        mask |= 1 << i;
+                    } else { pf.h[i][0].zero(); pf.h[i][1].zero(); }
+                } else {
+                    const int o = geom.off0[i];
                     if (o >= 0 && cs >= 0) {
-                        pf.h[i] = load_vec16(base + o + cs);
+                        int d1, d2;
+                        if constexpr (GSP == MRISR_SP_POOL2) { d1 = p.src[0].C; d2 = p.src[0].W * p.src[0].C; }
+                        else {
+                            d1 = ((upflags >> (2 * i + 1)) & 1) ? p.src[0].C : 0;
+                            d2 = ((upflags >> (2 * i)) & 1) ? p.src[0].W * p.src[0].C : 0;
+                        }
+                        const T* b = base + o + cs;
+                        pf.h[i][0] = load_vec16(b); pf.h[i][1] = load_vec16(b + d1);
+                        pf.h[i][2] = load_vec16(b + d2); pf.h[i][3] = load_vec16(b + d2 + d1);
                         mask |= 1 << i;
                     } else {
-                        pf.h[i].zero();
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pf.h[i][q].zero();
                     }
                 }
-                pf.mask = mask;
             }
+            pf.mask = mask;
         }
     };
     // transform + store the prefetched item into LDS (gather modes: stage synchronously)
-    auto commit = [&](int n, int kc) {
+    auto commit = [&](int n, int kc, int ty0, int tx0) {
         if (p.dbg & 2) return;
         if constexpr (!WS) {
 #pragma unroll
@@ -198,8 +234,38 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         if constexpr (pf_halo) {
 #pragma unroll
             for (int i = 0; i < kMaxHaloIter; ++i) {
-                Vec16<T> v = pf.h[i];
-                if ((pf.mask >> i) & 1) transform_vec(v, pf.mode, pf.sc, pf.sh);
+                Vec16<T> v = pf.h[i][0];
+                if ((pf.mask >> i) & 1) {
+                    if constexpr (NH == 1) {
+                        transform_vec(v, pf.mode, pf.sc, pf.sh);
+                    } else if constexpr (NH == 2) {
+                        float fa[VEC], fb[VEC];
+                        transform_f(pf.h[i][0], fa, p.src[0].mode, pf.sc, pf.sh);
+                        transform_f(pf.h[i][1], fb, p.src[1].mode, pf.sc1, pf.sh1);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v.set(e, blend_a * fa[e] + (1.f - blend_a) * fb[e]);
+                    } else {
+                        float f0[VEC], f1[VEC], f2[VEC], f3[VEC];
+                        transform_f(pf.h[i][0], f0, pf.mode, pf.sc, pf.sh);
+                        transform_f(pf.h[i][1], f1, pf.mode, pf.sc, pf.sh);
+                        transform_f(pf.h[i][2], f2, pf.mode, pf.sc, pf.sh);
+                        transform_f(pf.h[i][3], f3, pf.mode, pf.sc, pf.sh);
+                        if constexpr (GSP == MRISR_SP_POOL2) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) v.set(e, fmaxf(fmaxf(f0[e], f1[e]), fmaxf(f2[e], f3[e])));
+                        } else {
+                            // interpolation weights re-derived from the coordinates (cheaper than 12 live VGPRs)
+                            int i0, i1;
+                            float wy1, wx1;
+                            up2_coord(ty0 + (hyx[i] >> 16) - PAD - p.src[0].off_y, p.src[0].H, i0, i1, wy1);
+                            up2_coord(tx0 + (hyx[i] & 0xffff) - PAD - p.src[0].off_x, p.src[0].W, i0, i1, wx1);
+                            const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                v.set(e, wy0 * (wx0 * f0[e] + wx1 * f1[e]) + wy1 * (wx0 * f2[e] + wx1 * f3[e]));
+                        }
+                    }
+                }
                 if (hyx[i] >= 0) *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
             }
         } else {
@@ -297,7 +363,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 ep_pending = false;
             }
             if (c < nitems) {
-                commit(cur_n, cur_kc);
+                commit(cur_n, cur_kc, cur_ty0, cur_tx0);
                 nxt_tile = cur_tile; nxt_kc = cur_kc + 1; nxt_n = cur_n; nxt_ty0 = cur_ty0; nxt_tx0 = cur_tx0;
                 if (nxt_kc == p.nchunks) {
                     nxt_kc = 0;
@@ -453,7 +519,7 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
 }
 
 static int g_num_cus = 0;
-static int num_cus() {
+int num_cus() {
     if (!g_num_cus) {
         int dev = 0;
         hipDeviceProp_t prop;

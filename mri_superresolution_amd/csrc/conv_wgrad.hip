@@ -6,16 +6,25 @@
 // GEMM view per tap: M = co, N = ci, K = pixels.  Both operands are pixel-major (NHWC), i.e.
 // K-strided, so fragments come from LDS through the transposing read ds_read_b64_tr_b16 (bf16) or
 // single-dword reads (exact-fp32 32x32x2 MFMA).  The conv input is re-created by the same fused
-// loader as the forward pass (GroupNorm+LeakyReLU apply / pool / bilinear / concat / blend).
+// loader as the forward pass (GroupNorm+LeakyReLU apply / concat / blend; gathers staged synchronously).
 //
-// Workgroup = (co block, ci block) of 128-byte channel rows, looping over a slice of the pixel
-// tiles (split-K over the grid); partial sums are added to the fp32 master gradient with
-// 128-byte-segment float atomics (ci contiguous).
+// Workgroup = 8 waves on one (co block, ci block) of 128-byte channel rows, looping over a strided
+// slice of the 256-pixel tiles (split-K over the grid).  bf16: wave = (32x32 fragment pair, tap group
+// {0-4} / {5-8}), so the two waves that share a SIMD split the 9 taps and keep its matrix pipe busy
+// while the per-wave accumulator stays at 80 VGPRs - which leaves room to prefetch the next tile's
+// operands through registers while the MFMAs run.  LDS is double-buffered (one barrier per tile).
+// Partial sums are added to the fp32 master gradient with 128-byte-segment float atomics.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_t> { static constexpr int BC = 64; };   // channels per 128-B row
 template <> struct WgTraits<float> { static constexpr int BC = 32; };
+
+constexpr int kWgThreads = 512;
+constexpr int kWgSlots = 6;          // halo pixels per thread: slot i = halo pixel (t>>3) + 64 i
+static_assert(kWgSlots == kMaxHaloIter, "HaloGeom holds kMaxHaloIter slots");
 
 __device__ __forceinline__ bf16x8 tr_read_frag(const char* base0, const char* base1) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -27,22 +36,27 @@ __device__ __forceinline__ bf16x8 tr_read_frag(const char* base0, const char* ba
     return u.v;
 }
 
+constexpr int kLoaderBlendW = 3;     // template-only loader kind: sigmoid(alpha)-blend of two sources
+
 template <typename T, int SPATIAL, int KS>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_wgrad_kernel(const ConvParams p) {
+__global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams p = pin_params(p_in);
     constexpr int NTAPS = KS * KS;
+    constexpr int NT0 = (NTAPS + 1) / 2;      // taps of tap group 0 (group 1 takes the rest)
     constexpr int PAD = KS / 2;
     constexpr int BC = WgTraits<T>::BC;
     constexpr int VEC = Vec16<T>::N;
     constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int GSP = (SPATIAL == kLoaderBlendW) ? MRISR_SP_NONE : SPATIAL;
+    constexpr int NH = SPATIAL == MRISR_SP_NONE ? 1 : SPATIAL == kLoaderBlendW ? 2 : 0;   // prefetched vectors per slot
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int TW = 1 << p.tw_log2, TH = p.th;
     const int hw = TW + 2 * PAD, hh = TH + 2 * PAD;
     const int npix_halo = hw * hh;
-    char* lds_dy = smem;                       // [256 px][128 B]
-    char* lds_in = smem + 256 * 128;           // [halo px][128 B]
+    const int buf_bytes = 256 * 128 + npix_halo * 128;       // [dy 256 px][halo px], 128-B rows
 
     const int ncib = (p.Cin + BC - 1) / BC;
     const int cib = blockIdx.x % ncib, cob = blockIdx.x / ncib;
@@ -52,112 +66,222 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wgrad_kernel(const ConvP
     float blend_a = 0.f;
     if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
 
-    f32x16 acc[NTAPS];
+    // wave roles
+    const int tg = wave >> 2;                                 // tap group (1x1: K half)
+    const int fo = kBf16 ? ((wave >> 1) & 1) : 0, fi = kBf16 ? (wave & 1) : 0;
+    f32x16 acc[NT0];
 #pragma unroll
-    for (int tp = 0; tp < NTAPS; ++tp)
+    for (int i = 0; i < NT0; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // bf16: wave -> (co fragment, ci fragment); fp32: one fragment pair, waves split the pixels
-    const int fo = kBf16 ? (wave >> 1) : 0, fi = kBf16 ? (wave & 1) : 0;
-
-    for (int tile = blockIdx.y; tile < total_tiles; tile += gridDim.y) {
-        int b = tile;
-        const int tx = b % p.tiles_x; b /= p.tiles_x;
-        const int ty = b % p.tiles_y;
-        const int n = b / p.tiles_y;
-        const int ty0 = ty * TH, tx0 = tx * TW;
-
-        // ---- stage dy tile: thread -> 16-B chunk (t&7) of pixels (t>>3)+32i
-        {
-            const int ch = t & 7;
-            const int c = co0 + ch * VEC;
+    // staging roles: dy -> 16-B chunk (t&7) of pixels (t>>3) + 64 i, i < 4; halo -> chunk (t&7) of slots (t>>3) + 64 i
+    const int ch8 = t & 7;
+    int hyx[kWgSlots];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pl = (t >> 3) + 32 * i;
-                const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
-                Vec16<T> v;
-                v.zero();
-                if (oy < p.H && ox < p.W && c < p.Cout)
-                    v = load_vec16((const T*)p.dy + ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + c);
-                *reinterpret_cast<decltype(v.v)*>(lds_dy + lds_off128(pl, ch >> 2, ch & 3)) = v.v;
+    for (int i = 0; i < kWgSlots; ++i) {
+        const int hp = (t >> 3) + 64 * i;
+        const int hy = hp / hw;
+        hyx[i] = hp < npix_halo ? ((hy << 16) | (hp - hy * hw)) : -1;
+    }
+    HaloGeom<GSP> geom;
+    Vec16<T> pdy[4];
+    Vec16<T> ph[kWgSlots][NH > 0 ? NH : 1];
+    float sc[VEC], sh[VEC], sc1[NH == 2 ? VEC : 1], sh1[NH == 2 ? VEC : 1];
+    int pmask = 0, pmode = 0;
+
+    auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
+        const int tx = tile % p.tiles_x;
+        const int r = tile / p.tiles_x;
+        n = r / p.tiles_y;
+        ty0 = (r - n * p.tiles_y) * TH;
+        tx0 = tx * TW;
+    };
+    auto set_geom = [&](int n, int ty0, int tx0) {
+#pragma unroll
+        for (int i = 0; i < kWgSlots; ++i)
+            halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
+    };
+    // channel vector of this thread inside the conv input for the halo: sub-chunk (ch8>>2), chunk (ch8&3)
+    const int c_in = ci0 + ch8 * VEC;
+    auto issue = [&](int n, int ty0, int tx0) {
+        const int c = co0 + ch8 * VEC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pl = (t >> 3) + 64 * i;
+            const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
+            if (oy < p.H && ox < p.W && c < p.Cout)
+                pdy[i] = load_vec16((const T*)p.dy + ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + c);
+            else
+                pdy[i].zero();
+        }
+        if constexpr (NH > 0) {
+            int which = 0, cs = c_in;
+            if constexpr (NH == 1) {
+                if (p.nsrc > 1 && c_in >= p.src[0].C) { which = 1; cs = c_in - p.src[0].C; }
+            }
+            if (cs >= p.src[which].C) cs = -1;
+            load_affine<VEC>(p.src[which], n, cs, sc, sh);
+            if constexpr (NH == 2) load_affine<VEC>(p.src[1], n, cs, sc1, sh1);
+            pmode = p.src[which].mode;
+            const T* base = (const T*)p.src[which].ptr;
+            int mask = 0;
+#pragma unroll
+            for (int i = 0; i < kWgSlots; ++i) {
+                if constexpr (NH == 1) {
+                    const int o = which ? geom.off1[i] : geom.off0[i];
+                    if (o >= 0 && cs >= 0) { ph[i][0] = load_vec16(base + o + cs); mask |= 1 << i; }
+                    else ph[i][0].zero();
+                } else {
+                    const int o0 = geom.off0[i], o1 = geom.off1[i];
+                    if (o0 >= 0 && o1 >= 0 && cs >= 0) {
+                        ph[i][0] = load_vec16(base + o0 + cs);
+                        ph[i][1] = load_vec16((const T*)p.src[1].ptr + o1 + cs);
+                        mask |= 1 << i;
+                    } else { ph[i][0].zero(); ph[i][1].zero(); }
+                }
+            }
+            pmask = mask;
+        }
+    };
+    auto commit = [&](char* buf, int n) {
+        char* lds_dy = buf;
+        char* lds_in = buf + 256 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pl = (t >> 3) + 64 * i;
+            *reinterpret_cast<decltype(pdy[i].v)*>(lds_dy + lds_off128(pl, ch8 >> 2, ch8 & 3)) = pdy[i].v;
+        }
+        if constexpr (NH > 0) {
+#pragma unroll
+            for (int i = 0; i < kWgSlots; ++i) {
+                Vec16<T> v = ph[i][0];
+                if ((pmask >> i) & 1) {
+                    if constexpr (NH == 1) {
+                        transform_vec(v, pmode, sc, sh);
+                    } else {
+                        float fa[VEC], fb[VEC];
+                        transform_f(ph[i][0], fa, p.src[0].mode, sc, sh);
+                        transform_f(ph[i][1], fb, p.src[1].mode, sc1, sh1);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v.set(e, blend_a * fa[e] + (1.f - blend_a) * fb[e]);
+                    }
+                }
+                if (hyx[i] >= 0)
+                    *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128((t >> 3) + 64 * i, ch8 >> 2, ch8 & 3)) = v.v;
+            }
+        } else {
+            // gathers (pool / bilinear): load + transform + store here, one slot at a time
+            int cs = c_in;
+            if (cs >= p.src[0].C) cs = -1;
+            load_affine<VEC>(p.src[0], n, cs, sc, sh);
+#pragma unroll
+            for (int i = 0; i < kWgSlots; ++i) {
+                const Vec16<T> v = halo_load<T, GSP>(geom, i, c_in, p, sc, sh, sc, sh, blend_a, 0, cs);
+                if (hyx[i] >= 0)
+                    *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128((t >> 3) + 64 * i, ch8 >> 2, ch8 & 3)) = v.v;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the staging phases apart: 144 accumulator VGPRs are live
-        // ---- stage the transformed input halo: two 64-B cin sub-chunks
-        {
-            HaloGeom<SPATIAL> geom;
-#pragma unroll
-            for (int i = 0; i < kMaxHaloIter; ++i)
-                halo_geom_init<SPATIAL>(geom, i, (t >> 2) + 64 * i, npix_halo, hw, PAD, n, ty0, tx0, p);
-            stage_halo<T, SPATIAL, 128, 2>(lds_in, geom, 2 * cib, n, npix_halo, blend_a, p, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_halo<T, SPATIAL, 128, 2>(lds_in, geom, 2 * cib + 1, n, npix_halo, blend_a, p, 1);
-        }
-        __syncthreads();
+    };
 
+    int tile = blockIdx.y, n = 0, ty0 = 0, tx0 = 0, cur = 0;
+    if (tile < total_tiles) {
+        decode(tile, n, ty0, tx0);
+        set_geom(n, ty0, tx0);
+        issue(n, ty0, tx0);
+        commit(smem, n);
+    }
+    __syncthreads();
+    while (tile < total_tiles) {
+        const int nxt = tile + gridDim.y;
+        const bool has_next = nxt < total_tiles;
+        int nn = n, nty0 = ty0, ntx0 = tx0;
+        if (has_next) {
+            decode(nxt, nn, nty0, ntx0);
+            set_geom(nn, nty0, ntx0);
+            issue(nn, nty0, ntx0);              // global loads fly while the MFMAs below run
+        }
+        const char* lds_dy = smem + cur * buf_bytes;
+        const char* lds_in = lds_dy + 256 * 128;
         if constexpr (kBf16) {
             const int li = lane & 15, gq = li >> 2, gp = li & 3, gr = (lane >> 4) & 1;
-            // 16 pixels per k-step; this lane addresses pixel k0 + 8*lh + 4*t + gq, channels 16*gr+4*gp
             const int chb = 16 * gr + 4 * gp;            // channel inside the 32-wide fragment
+            const int c_dy = fo * 32 + chb, c_b = fi * 32 + chb;
+            // 1x1: both groups take the single tap and split the k-steps
+            const int ks_lo = NTAPS == 1 ? 8 * tg : 0, ks_hi = NTAPS == 1 ? 8 * tg + 8 : 16;
 #pragma unroll 1
-            for (int ks = 0; ks < 16; ++ks) {
-                const int pk = ks * 16 + 8 * lh + gq;    // pixel (t = 0); t = 1 adds 4
-                const int c_dy = fo * 32 + chb;          // channel within the 64-wide row
+            for (int ks = ks_lo; ks < ks_hi; ++ks) {
+                const int pk = ks * 16 + 8 * lh + gq;    // pixel (second read: +4)
                 const bf16x8 af = tr_read_frag(
                     lds_dy + lds_off128(pk, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1),
                     lds_dy + lds_off128(pk + 4, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1));
                 const int hp = (pk >> p.tw_log2) * hw + (pk & (TW - 1));   // pk and pk+4 share the row
-                const int c_in = fi * 32 + chb;
 #pragma unroll
-                for (int tap = 0; tap < NTAPS; ++tap) {
-                    const int h0 = hp + (tap / KS) * hw + (tap % KS);
-                    const bf16x8 bfr = tr_read_frag(
-                        lds_in + lds_off128(h0, c_in >> 5, (c_in >> 3) & 3) + ((c_in & 4) << 1),
-                        lds_in + lds_off128(h0 + 4, c_in >> 5, (c_in >> 3) & 3) + ((c_in & 4) << 1));
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tap], 0, 0, 0);
+                for (int j = 0; j < NT0; ++j) {
+                    const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);
+                    if (tap < NTAPS) {
+                        const int h0 = hp + (tap / KS) * hw + (tap % KS);
+                        const bf16x8 bfr = tr_read_frag(
+                            lds_in + lds_off128(h0, c_b >> 5, (c_b >> 3) & 3) + ((c_b & 4) << 1),
+                            lds_in + lds_off128(h0 + 4, c_b >> 5, (c_b >> 3) & 3) + ((c_b & 4) << 1));
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                    }
                 }
             }
         } else {
-            // exact fp32: one 32x32x2 MFMA per pixel pair; wave w takes pairs w, w+4, ...
-            for (int kp = wave; kp < 128; kp += 4) {
+            // exact fp32: one 32x32x2 MFMA per pixel pair and tap; wave (tg, kq) takes pairs kq, kq+4, ...
+            const int kq = wave & 3;
+            const int kp_lo = NTAPS == 1 ? 64 * tg + kq : kq, kp_hi = NTAPS == 1 ? 64 * tg + 64 : 128;
+            for (int kp = kp_lo; kp < kp_hi; kp += 4) {
                 const int pk = 2 * kp + lh;
                 const float a = *reinterpret_cast<const float*>(lds_dy + lds_off128(pk, lr >> 4, (lr >> 2) & 3) + ((lr & 3) << 2));
                 const int hp = (pk >> p.tw_log2) * hw + (pk & (TW - 1));
 #pragma unroll
-                for (int tap = 0; tap < NTAPS; ++tap) {
-                    const int h0 = hp + (tap / KS) * hw + (tap % KS);
-                    const float bb = *reinterpret_cast<const float*>(lds_in + lds_off128(h0, lr >> 4, (lr >> 2) & 3) + ((lr & 3) << 2));
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[tap], 0, 0, 0);
+                for (int j = 0; j < NT0; ++j) {
+                    const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);
+                    if (tap < NTAPS) {
+                        const int h0 = hp + (tap / KS) * hw + (tap % KS);
+                        const float bb = *reinterpret_cast<const float*>(lds_in + lds_off128(h0, lr >> 4, (lr >> 2) & 3) + ((lr & 3) << 2));
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[j], 0, 0, 0);
+                    }
                 }
             }
         }
+        if (has_next) commit(smem + (cur ^ 1) * buf_bytes, nn);
         __syncthreads();
+        cur ^= 1;
+        tile = nxt; n = nn; ty0 = nty0; tx0 = ntx0;
     }
 
     // ---- accumulate into dW[co][tap][ci]: lane = ci (128-B contiguous per half wave), regs = co
     const int ci = ci0 + fi * 32 + lr;
     if (ci < p.Cin) {
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap)
+        for (int j = 0; j < NT0; ++j) {
+            const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);
+            if (tap < NTAPS) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.Cout) atomic_add_f32(p.dw + ((size_t)co * NTAPS + tap) * p.Cin + ci, acc[tap][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (co < p.Cout) atomic_add_f32(p.dw + ((size_t)co * NTAPS + tap) * p.Cin + ci, acc[j][r]);
+                }
             }
+        }
     }
 }
 
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who);
+int num_cus();
 
 template <typename T, int SPATIAL, int KS>
 static int launch_wgrad(ConvParams& p, hipStream_t s) {
     constexpr int BC = WgTraits<T>::BC;
     const int TW = 1 << p.tw_log2, pad = KS / 2;
-    const size_t lds = 256 * 128 + (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * 128;
+    const size_t lds = 2 * (256 * 128 + (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * 128);
     const int nblk = ceil_div(p.Cout, BC) * ceil_div(p.Cin, BC);
     const int total_tiles = p.N * p.tiles_y * p.tiles_x;
-    int ksplit = ceil_div(512, nblk);
+    int ksplit = ceil_div(num_cus(), nblk);          // one 8-wave workgroup per CU (LDS-limited)
     if (ksplit > total_tiles) ksplit = total_tiles;
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 65535) ksplit = 65535;
@@ -167,13 +291,17 @@ static int launch_wgrad(ConvParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk, ksplit), dim3(kConvThreads), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblk, ksplit), dim3(kWgThreads), lds, s, p);
     MRISR_CHECK_LAUNCH("conv_wgrad");
     return MRISR_OK;
 }
 
 template <typename T>
 static int dispatch_wgrad(ConvParams& p, int spatial, int ks, hipStream_t s) {
+    if (p.combine == MRISR_COMBINE_BLEND) {
+        if (ks != 3) MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_wgrad: blend needs a 3x3 conv");
+        return launch_wgrad<T, kLoaderBlendW, 3>(p, s);
+    }
     if (ks == 3) {
         if (spatial == MRISR_SP_NONE) return launch_wgrad<T, MRISR_SP_NONE, 3>(p, s);
         if (spatial == MRISR_SP_POOL2) return launch_wgrad<T, MRISR_SP_POOL2, 3>(p, s);

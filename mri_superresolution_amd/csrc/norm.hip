@@ -649,3 +649,57 @@ extern "C" int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, 
     MRISR_CHECK_LAUNCH("upsample2_adjoint");
     return MRISR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// out [N][2h][2w][C] = bilinear x2 (align_corners=True) of LeakyReLU(x*scale+shift): materialises the input of
+// final_up_bilinear's 3x3 conv (unet_model.py:151-152).  Gathering 4 taps per element inside the conv loader of a
+// 32-channel-wide layer is load-bound, so here the interpolated activation is written once and the conv (and
+// its weight gradient) run on the plain prefetching loader.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_upsample2_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ out, int N,
+                                                             int h, int w, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = C / VEC, H = 2 * h, W = 2 * w;
+    const size_t total = (size_t)N * H * W * nvec;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        size_t r = idx / nvec;
+        const int X = r % W; r /= W;
+        const int Y = r % H;
+        const int n = r / H;
+        const int c = cv * VEC;
+        int y0, y1, x0, x1;
+        float wy, wx;
+        up2_coord(Y, h, y0, y1, wy);
+        up2_coord(X, w, x0, x1, wx);
+        float sc[VEC], sh[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
+        const T* b = x + (size_t)n * h * w * C + c;
+        const Vec16<T> v00 = load_vec16(b + ((size_t)y0 * w + x0) * C), v01 = load_vec16(b + ((size_t)y0 * w + x1) * C);
+        const Vec16<T> v10 = load_vec16(b + ((size_t)y1 * w + x0) * C), v11 = load_vec16(b + ((size_t)y1 * w + x1) * C);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float a = lrelu(v00.get(e) * sc[e] + sh[e]), bq = lrelu(v01.get(e) * sc[e] + sh[e]);
+            const float cq = lrelu(v10.get(e) * sc[e] + sh[e]), d = lrelu(v11.get(e) * sc[e] + sh[e]);
+            o.set(e, (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * cq + wx * d));
+        }
+        store_vec16(out + idx * VEC, o);
+    }
+}
+
+extern "C" int mrisr_norm_upsample2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
+                                    int h, int w, int C, void* stream) {
+    if (!x || !scale || !shift || !out) MRISR_FAIL(MRISR_E_ARG, "norm_upsample2: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d", C);
+    const size_t total = (size_t)N * 4 * h * w * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == MRISR_BF16) norm_upsample2_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, h, w, C);
+    else if (dtype == MRISR_F32) norm_upsample2_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, h, w, C);
+    else MRISR_FAIL(MRISR_E_DTYPE, "norm_upsample2: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("norm_upsample2");
+    return MRISR_OK;
+}

@@ -68,6 +68,7 @@ class Layer:
     bias: bool = False
     out_mode: int = L.OUT_PLAIN
     pool_src: bool = False      # source = materialised MaxPool2d(2) of the activated source node (encoder)
+    up_src: bool = False        # source = materialised bilinear x2 of the activated source node (final_up_bilinear)
     post_up: bool = False       # 1x1 conv evaluated at low resolution, bilinear x2 applied to its output
     # per-forward geometry / saved tensors
     H: int = 0
@@ -158,7 +159,7 @@ class UNetEngine:
             u = dconv(f"up{j}.conv", [Source(skip), Source(up)], 2 * cout, cout)
         # dual-branch head (unet_model.py:150-173)
         fb = node("final_up_bilinear.1", f // 2, "final_up_bilinear.2.weight", "final_up_bilinear.2.bias")
-        self.layers.append(Layer("final_up_bilinear.1", f, f // 2, 3, [Source(u, L.SP_UP2)], fb))
+        self.layers.append(Layer("final_up_bilinear.1", f, f // 2, 3, [Source(u)], fb, up_src=True))
         ps = node("final_up_pixelshuffle.conv", f // 2, "final_up_pixelshuffle.norm.weight",
                   "final_up_pixelshuffle.norm.bias", shuffled=True)
         self.layers.append(Layer("final_up_pixelshuffle.conv", f, 2 * f, 3, [Source(u)], ps, bias=True,
@@ -202,7 +203,7 @@ class UNetEngine:
         d.combine, d.out_mode, d.groups, d.relu_out = layer.combine, layer.out_mode, GN_GROUPS, 0
         for i, (s, (oy, ox)) in enumerate(zip(layer.srcs, layer.offs)):
             n = s.node
-            if layer.pool_src:          # materialised pooled activation: a plain tensor
+            if layer.pool_src or layer.up_src:      # materialised pooled / upsampled activation: a plain tensor
                 d.src[i].ptr = layer.aux.data_ptr()
                 d.src[i].C, d.src[i].H, d.src[i].W = n.C, layer.H, layer.W
                 d.src[i].mode, d.src[i].spatial = L.SRC_RAW, L.SP_NONE
@@ -268,10 +269,16 @@ class UNetEngine:
                 layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
                 L.call("mrisr_norm_pool2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
                        layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st)
+            if layer.up_src:
+                sn = layer.srcs[0].node
+                vh, vw = 2 * sn.H, 2 * sn.W
+                layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
+                L.call("mrisr_norm_upsample2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
+                       layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st)
             layer.H, layer.W = vh, vw
             layer.offs = []
             for sidx, src in enumerate(layer.srcs):
-                h, w = (vh, vw) if layer.pool_src else self._virtual_hw(src)
+                h, w = (vh, vw) if (layer.pool_src or layer.up_src) else self._virtual_hw(src)
                 dy, dx = vh - h, vw - w
                 if dy < 0 or dx < 0:
                     raise RuntimeError(f"{layer.name}: source larger than the conv input")
@@ -412,7 +419,7 @@ class UNetEngine:
             else:
                 coff = 0
                 for src, (oy, ox) in zip(layer.srcs, layer.offs):
-                    sp = L.SP_POOL2 if layer.pool_src else src.spatial
+                    sp = L.SP_POOL2 if layer.pool_src else (L.SP_UP2 if layer.up_src else src.spatial)
                     src.node.consumers.append((dain, layer.cin, coff, layer.H, layer.W, sp, oy, ox, 0))
                     coff += src.node.C
             if bucket_hook:
