@@ -66,9 +66,14 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     float blend_a = 0.f;
     if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
 
-    // wave roles
+    // wave roles: tap group, 32x32 fragment pair, and - when the channel block holds fewer than 4 pairs
+    // (Cout or Cin <= 32) - a share of the k-steps, so no wave multiplies padding
     const int tg = wave >> 2;                                 // tap group (1x1: K half)
-    const int fo = kBf16 ? ((wave >> 1) & 1) : 0, fi = kBf16 ? (wave & 1) : 0;
+    const int nfo = kBf16 ? (min(p.Cout - co0, BC) > 32 ? 2 : 1) : 1;
+    const int nfi = kBf16 ? (min(p.Cin - ci0, BC) > 32 ? 2 : 1) : 1;
+    const int npairs = nfo * nfi, kparts = 4 / npairs;        // 1, 2 or 4 pairs
+    const int pair = (wave & 3) % npairs, kpart = (wave & 3) / npairs;
+    const int fo = pair / nfi, fi = pair % nfi;
     f32x16 acc[NT0];
 #pragma unroll
     for (int i = 0; i < NT0; ++i)
@@ -209,9 +214,9 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             const int chb = 16 * gr + 4 * gp;            // channel inside the 32-wide fragment
             const int c_dy = fo * 32 + chb, c_b = fi * 32 + chb;
             // 1x1: both groups take the single tap and split the k-steps
-            const int ks_lo = NTAPS == 1 ? 8 * tg : 0, ks_hi = NTAPS == 1 ? 8 * tg + 8 : 16;
+            const int ks_lo = (NTAPS == 1 ? 8 * tg : 0) + kpart, ks_hi = NTAPS == 1 ? 8 * tg + 8 : 16;
 #pragma unroll 1
-            for (int ks = ks_lo; ks < ks_hi; ++ks) {
+            for (int ks = ks_lo; ks < ks_hi; ks += kparts) {
                 const int pk = ks * 16 + 8 * lh + gq;    // pixel (second read: +4)
                 const bf16x8 af = tr_read_frag(
                     lds_dy + lds_off128(pk, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1),

@@ -69,11 +69,13 @@ __device__ __forceinline__ void act_of(const T* p, const float* sc, const float*
     for (int e = 0; e < Vec16<T>::N; ++e) o[e] = lrelu(v.get(e) * sc[e] + sh[e]);
 }
 
-// candidate high-res rows of a bilinear x2 (align_corners) adjoint and their weights for low-res index y
+// candidate high-res rows of a bilinear x2 (align_corners) adjoint and their weights for low-res index y:
+// src(Y) = Y (n-1)/(2n-1) touches row y only for Y in [2y-1, 2y+2] (checked exhaustively for n <= 512)
+constexpr int kUpAdj = 4;
 __device__ __forceinline__ void up2_adjoint_weights(int y, int in_size, int* idx, float* w) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int Y = 2 * y - 2 + k;
+    for (int k = 0; k < kUpAdj; ++k) {
+        const int Y = 2 * y - 1 + k;
         float wt = 0.f;
         if (Y >= 0 && Y < 2 * in_size) {
             int i0, i1;
@@ -162,15 +164,15 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
                         }
                     }
                 } else {   // adjoint of bilinear x2 (align_corners=True)
-                    int iy[6], ix[6];
-                    float wy[6], wx[6];
+                    int iy[kUpAdj], ix[kUpAdj];
+                    float wy[kUpAdj], wx[kUpAdj];
                     up2_adjoint_weights(y, p.H, iy, wy);
                     up2_adjoint_weights(x, p.W, ix, wx);
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) {
+                    for (int a = 0; a < kUpAdj; ++a) {
                         if (wy[a] == 0.f) continue;
 #pragma unroll
-                        for (int b = 0; b < 6; ++b) {
+                        for (int b = 0; b < kUpAdj; ++b) {
                             if (wx[b] == 0.f) continue;
                             const int yy = iy[a] + cs.off_y, xx = ix[b] + cs.off_x;
                             const Vec16<T> d = load_vec16(dab + ((size_t)yy * cs.W + xx) * cs.C_total);
@@ -610,8 +612,8 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restr
         const int x = r % w; r /= w;
         const int y = r % h;
         const int n = r / h;
-        int iy[6], ix[6];
-        float wy[6], wx[6];
+        int iy[kUpAdj], ix[kUpAdj];
+        float wy[kUpAdj], wx[kUpAdj];
         up2_adjoint_weights(y, h, iy, wy);
         up2_adjoint_weights(x, w, ix, wx);
         float acc[VEC];
@@ -619,10 +621,10 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restr
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
         const T* b = dz + (size_t)n * 4 * h * w * C + cv * VEC;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
+        for (int a = 0; a < kUpAdj; ++a) {
             if (wy[a] == 0.f) continue;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
+            for (int q = 0; q < kUpAdj; ++q) {
                 if (wx[q] == 0.f) continue;
                 const Vec16<T> d = load_vec16(b + ((size_t)iy[a] * (2 * w) + ix[q]) * C);
                 const float wv = wy[a] * wx[q];

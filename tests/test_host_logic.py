@@ -1,0 +1,150 @@
+"""CPU-only tests of the host logic: C-ABI symbol table, module/state_dict contract, flat parameter storage,
+loss argument validation, CLI flags, data-parallel bucketing over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mri_superresolution_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "mrisr.h")).read()
+    declared = set(re.findall(r"\b(mrisr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mrisr_src", "mrisr_conv_desc", "mrisr_consumer"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().mrisr_version() >= 100
+    # argument validation works without a GPU (no launch happens)
+    assert _lib.load().mrisr_pack_weights(0, None, 8, 8, 3, 0, None, None) == -1
+    assert b"null" in _lib.load().mrisr_last_error()
+    # struct layouts match the header (sizes as compiled by the C side are fixed by the field lists)
+    assert ctypes.sizeof(_lib.Src) == 56 and ctypes.sizeof(_lib.Consumer) == 40
+
+
+def test_module_contract_matches_reference_spec():
+    from mri_superresolution_amd.models.unet_model import UNet, UNetSuperRes, DoubleConv, Down, Up, PixelShuffleUp, icnr
+    from oracle.unet_ref import formula_state_dict, state_dict_spec
+    assert UNet is UNetSuperRes
+    m = UNetSuperRes(in_channels=1, out_channels=1, base_filters=32, initial_alpha=50.0)
+    sd = m.state_dict()
+    spec = state_dict_spec(32)
+    assert list(sd.keys()) == list(spec.keys())
+    assert all(tuple(sd[k].shape) == tuple(spec[k]) for k in spec)
+    assert sum(p.numel() for p in m.parameters()) == 1_823_122
+    assert abs(float(m.alpha) - 0.5) < 1e-7 and (m.in_channels, m.out_channels, m.base_filters) == (1, 1, 32)
+    # flat storage: every parameter is a view of flat_params; conv weights are channels-last
+    base = m.flat_params.untyped_storage().data_ptr()
+    assert all(p.untyped_storage().data_ptr() == base for p in m.parameters())
+    w = m.inc.double_conv[3].weight
+    assert w.shape == (32, 32, 3, 3) and w.stride() == (288, 1, 96, 32)
+    ref = formula_state_dict(32, 7)
+    m.load_state_dict(ref)
+    assert all(torch.equal(m.state_dict()[k], ref[k]) for k in ref)
+    off, n = m._offsets["up2.conv.double_conv.0.weight"]
+    assert torch.equal(m.flat_params[off:off + n].view(64, 3, 3, 128), ref["up2.conv.double_conv.0.weight"].permute(0, 2, 3, 1))
+    # kaiming fan_out init statistics (reference unet_model.py:181) and GN (1, 0)
+    m2 = UNetSuperRes(base_filters=64)
+    w = m2.down2.maxpool_conv[1].double_conv[0].weight
+    assert abs(float(w.std()) - (2.0 / (256 * 9)) ** 0.5) < 0.05 * (2.0 / (256 * 9)) ** 0.5
+    assert torch.all(m2.up1.up[2].weight == 1) and torch.all(m2.up1.up[2].bias == 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 16, 16))
+    with pytest.raises(ValueError):
+        UNetSuperRes(base_filters=24)
+    t = torch.empty(8, 4, 3, 3)
+    icnr(t)
+    assert torch.equal(t[0], t[3]) and not torch.equal(t[0], t[4])
+    assert isinstance(DoubleConv(4, 8), torch.nn.Module) and Down and Up and PixelShuffleUp
+
+
+def test_loss_api_validation_and_window():
+    from mri_superresolution_amd.utils import losses
+    assert abs(float(losses.gaussian_window(11, 1.5)[5]) - 0.266012) < 1e-6
+    assert losses.create_window(11, 3, 1.5, torch.device("cpu")).shape == (3, 1, 11, 11)
+    assert losses.VGG_MEAN == [0.485, 0.456, 0.406]
+    for bad in ((-0.1, 0.0), (0.0, 1.5), (0.7, 0.6)):
+        with pytest.raises(ValueError):
+            losses.CombinedLoss(ssim_weight=bad[0], perceptual_weight=bad[1])
+    c = losses.CombinedLoss(ssim_weight=0.3)
+    assert abs(c.l1_weight - 0.7) < 1e-12 and "window" in dict(c.named_buffers())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        c(torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 16, 16))
+    with pytest.raises(NotImplementedError):
+        losses.CombinedLoss(ssim_weight=0.3, perceptual_weight=0.1)
+
+
+def test_cli_flags_match_reference():
+    sys.path.insert(0, REPO)
+    from scripts import infer, train
+    a = train.parse_args(["--full_res_dir", "a", "--low_res_dir", "b"])
+    assert (a.model_type, a.base_filters, a.batch_size, a.epochs, a.learning_rate, a.weight_decay) == ("unet", 32, 8, 100, 1e-4, 1e-5)
+    assert (a.ssim_weight, a.perceptual_weight, a.vgg_layer_idx, a.perceptual_loss_type) == (0.3, 0.0, 35, "l1")
+    assert (a.initial_alpha, a.validation_split, a.patience, a.checkpoint_dir, a.log_dir) == (0.0, 0.2, 10, "./checkpoints", "./logs")
+    assert not (a.augmentation or a.use_tensorboard or a.use_amp or a.cpu) and 1 <= a.seed <= 10000
+    b = infer.parse_args(["--input", "i.png", "--output", "o.png"])
+    assert (b.base_filters, b.model_type, b.checkpoint_dir, b.checkpoint_path, b.target) == (64, "unet", "./checkpoints", None, None)
+    x = np.array([[0.0, 10.0], [20.0, 1000.0]], dtype=np.float32)
+    y = infer.normalise_percentile(x)
+    assert y.min() == 0.0 and y.max() == 1.0
+    src, ref = np.array([[0.1, 0.2], [0.3, 0.4]]), np.array([[1.0, 2.0], [3.0, 4.0]])
+    assert np.allclose(infer.match_histograms(src, ref), ref)
+
+
+def test_shard_indices_cover_dataset():
+    from mri_superresolution_amd.parallel import shard_indices
+    parts = [shard_indices(10, r, 4, epoch=3, seed=1) for r in range(4)]
+    assert all(len(p) == 3 for p in parts)
+    assert set(sum(parts, [])) == set(range(10))
+    assert shard_indices(10, 1, 4, epoch=3, seed=1) == parts[1] != shard_indices(10, 1, 4, epoch=4, seed=1)
+
+
+_GLOO_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from mri_superresolution_amd.models.unet_model import UNetSuperRes
+from mri_superresolution_amd.parallel import DataParallel
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
+m = UNetSuperRes(base_filters=16)
+dp = DataParallel(m, bucket_bytes=200_000)
+ref = [torch.zeros_like(m.flat_params) for _ in range(world)]
+dist.all_gather(ref, m.flat_params)
+assert all(torch.equal(r, ref[0]) for r in ref), "weights not broadcast"
+assert len(dp.bucketer.bounds) > 3, dp.bucketer.bounds
+# fake a backward: rank-dependent gradient, layers reported in reverse execution order like the engine does
+m.flat_grads.copy_(torch.arange(m.flat_grads.numel(), dtype=torch.float32) * (rank + 1) * 1e-6)
+order = ["final_conv.3"] + [l.name for l in reversed(m._engine.layers)] + ["inc.double_conv.0"]
+launched = []
+for name in order:
+    dp.bucketer.on_layer_done(name)
+    launched.append(len(dp.bucketer.handles))
+assert launched[-1] >= 3 and launched[0] <= 1, launched       # buckets go out progressively (overlap)
+dp.finish_gradients()
+expect = torch.arange(m.flat_grads.numel(), dtype=torch.float32) * 1e-6 * sum(r + 1 for r in range(world))
+assert torch.allclose(m.flat_grads, expect, rtol=1e-6), (m.flat_grads - expect).abs().max()
+avg = dp.average_scalars(torch.tensor([float(rank), 2.0]))
+assert torch.allclose(avg, torch.tensor([(world - 1) / 2.0, 2.0]))
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_data_parallel_bucketed_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, REPO=REPO, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("OK") == 2
