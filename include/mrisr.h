@@ -48,6 +48,10 @@ extern "C" {
 #define MRISR_SP_UP2 2       /* bilinear x2, align_corners=True         (unet_model.py:71,151)*/
 #define MRISR_COMBINE_CONCAT 0 /* torch.cat([src0, src1], 1)            (unet_model.py:93)    */
 #define MRISR_COMBINE_BLEND 1  /* sigmoid(a)*src0 + (1-sigmoid(a))*src1 (unet_model.py:206-7) */
+/* GroupNorm statistics buffers are [MRISR_STAT_SLOTS][N][groups][2] doubles (sum, sum of squares): producers
+ * spread their atomics over the slots (same-address fp64 atomics serialise at ~170 ns each on gfx950),
+ * mrisr_gn_finalize adds the slots up.  Zero the whole buffer before use.                                  */
+#define MRISR_STAT_SLOTS 16
 #define MRISR_OUT_PLAIN 0
 #define MRISR_OUT_PIXEL_SHUFFLE2 1 /* out[n,2y+i,2x+j,c/4] = conv[n,y,x,c], c=4c'+2i+j (unet_model.py:102) */
 
@@ -76,7 +80,7 @@ typedef struct {
     const void* wpacked;    /* from mrisr_pack_weights                                         */
     const float* bias;      /* [Cout] or NULL                                                  */
     void* out;              /* NHWC [N][H][W][Cout] (or pixel-shuffled [N][2H][2W][Cout/4])    */
-    double* stats;          /* [N][groups][2] running (sum, sum of squares), accumulated; or NULL */
+    double* stats;          /* [MRISR_STAT_SLOTS][N][groups][2] (sum, sum of squares), accumulated; or NULL */
 } mrisr_conv_desc;
 
 const char* mrisr_last_error(void);
@@ -102,7 +106,7 @@ int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float* dw,
                      int N, int H, int W, int Cout, void* stream);
 
 /* ---- GroupNorm(8,C)+LeakyReLU(0.2): statistics -> per-(n,c) affine (unet_model.py:30-31) -- */
-/* stats [N][G][2] double -> scale/shift [N][C] fp32, meanrstd [N][G][2] fp32; count = (C/G)*H*W */
+/* stats [MRISR_STAT_SLOTS][N][G][2] double -> scale/shift [N][C] fp32, meanrstd [N][G][2] fp32; count = (C/G)*H*W */
 int mrisr_gn_finalize(const double* stats, const float* gamma, const float* beta, float* scale,
                       float* shift, float* meanrstd, int N, int C, int groups, double count,
                       float eps, void* stream);

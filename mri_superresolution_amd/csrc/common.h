@@ -114,4 +114,9 @@ __device__ __forceinline__ void up2_coord(int dst, int in_size, int& i0, int& i1
     w1 = src - (float)i0;
 }
 
+// slot of a statistics buffer for this workgroup (spreads same-address fp64 atomics)
+__device__ __forceinline__ size_t stat_slot_off(int N, int groups) {
+    return (size_t)((blockIdx.x + blockIdx.y) & (MRISR_STAT_SLOTS - 1)) * N * groups * 2;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

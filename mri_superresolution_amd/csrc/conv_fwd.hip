@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     };
     int upflags = 0;      // UP2 gather prefetch: bit 2i = second row differs, bit 2i+1 = second column differs
     auto set_geom = [&](int n, int ty0, int tx0) {
+        if (p.dbg & 32) return;
 #pragma unroll
         for (int i = 0; i < kMaxHaloIter; ++i)
             halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
@@ -281,8 +282,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 const float s = half_wave_sum(st_s[ni][q]), ss = half_wave_sum(st_ss[ni][q]);
                 if (lr == 0 && co < p.Cout) {
                     const int g = co / gs;
-                    atomic_add_f64(&p.stats[((size_t)n * p.groups + g) * 2], (double)s);
-                    atomic_add_f64(&p.stats[((size_t)n * p.groups + g) * 2 + 1], (double)ss);
+                    double* sp = p.stats + stat_slot_off(p.N, p.groups) + ((size_t)n * p.groups + g) * 2;
+                    atomic_add_f64(sp, (double)s);
+                    atomic_add_f64(sp + 1, (double)ss);
                 }
                 st_s[ni][q] = 0.f;
                 st_ss[ni][q] = 0.f;
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     };
     // epilogue of a finished tile: bias, (relu), NHWC / pixel-shuffled store, per-lane GroupNorm partial sums
     auto epilogue = [&](int n, int ty0, int tx0) {
+        if (p.dbg & 16) return;
         T* outp = (T*)p.out;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
             cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
         }
-        __syncthreads();
+        if (!(p.dbg & 64)) __syncthreads();
     }
 }
 

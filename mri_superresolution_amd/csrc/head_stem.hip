@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             }
         }
         __syncthreads();
-        for (int i = t; i < groups * 2; i += 256) atomic_add_f64(&stats[(size_t)n * groups * 2 + i], (double)sst[i]);
+        for (int i = t; i < groups * 2; i += 256)
+            atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], (double)sst[i]);
     }
 }
 
@@ -67,7 +68,7 @@ extern "C" int mrisr_stem_forward(int dtype, const float* x, const float* w, voi
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (Cout % vec || Cout / vec > 256 || (stats && (groups <= 0 || Cout % groups))) MRISR_FAIL(MRISR_E_SHAPE, "stem_forward: Cout %d", Cout);
     const int ppb = 256 / (Cout / vec);
-    int ppblk = ppb * 8;
+    int ppblk = ppb * 64;
     dim3 grid(ceil_div(H * W, ppblk), N);
     const size_t lds = (size_t)(Cout * 9 + (groups > 0 ? groups : 0) * 2) * sizeof(float);
     if (dtype == MRISR_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, H, W, Cout, groups, ppblk);

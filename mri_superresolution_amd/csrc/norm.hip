@@ -19,7 +19,11 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float
     if (idx >= N * C) return;
     const int n = idx / C, c = idx - n * C;
     const int gs = C / groups, g = c / gs;
-    const double s = stats[((size_t)n * groups + g) * 2], ss = stats[((size_t)n * groups + g) * 2 + 1];
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < MRISR_STAT_SLOTS; ++k) {
+        s += stats[((size_t)(k * N + n) * groups + g) * 2];
+        ss += stats[((size_t)(k * N + n) * groups + g) * 2 + 1];
+    }
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0) var = 0;
@@ -468,7 +472,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         atomicAdd(&lds[2 * (c / gs) + 1], ss);
     }
     __syncthreads();
-    for (int i = t; i < groups * 2; i += 256) atomic_add_f64(&stats[(size_t)n * groups * 2 + i], (double)lds[i]);
+    for (int i = t; i < groups * 2; i += 256)
+        atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], (double)lds[i]);
 }
 
 int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s) {
@@ -580,7 +585,8 @@ __global__ __launch_bounds__(256) void upsample2_stats_kernel(const T* __restric
             }
         }
         __syncthreads();
-        for (int i = t; i < groups * 2; i += 256) atomic_add_f64(&stats[(size_t)n * groups * 2 + i], (double)lds[i]);
+        for (int i = t; i < groups * 2; i += 256)
+            atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], (double)lds[i]);
     }
 }
 

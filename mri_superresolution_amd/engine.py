@@ -238,9 +238,10 @@ class UNetEngine:
         st = L.stream_ptr()
         f = self.f
         nodes = list(self.nodes.values())
-        arena = torch.zeros(len(nodes) * N * GN_GROUPS * 2, dtype=torch.float64, device=dev)
+        per = L.STAT_SLOTS * N * GN_GROUPS * 2
+        arena = torch.zeros(len(nodes) * per, dtype=torch.float64, device=dev)
         for i, n in enumerate(nodes):
-            n.stats = arena[i * N * GN_GROUPS * 2:(i + 1) * N * GN_GROUPS * 2]
+            n.stats = arena[i * per:(i + 1) * per]
             n.consumers = []
 
         def finalize(n: Node):

@@ -124,12 +124,12 @@ def conv_forward(dt, srcs, w, H, W, ks, bias=None, combine=L.COMBINE_CONCAT, out
     else:
         out = torch.full((N, H, W, cout), float("nan"), dtype=tdt(dt), device=DEV)
     d.out = out.data_ptr()
-    stats = torch.zeros(N * 8 * 2, dtype=torch.float64, device=DEV)
+    stats = torch.zeros(L.STAT_SLOTS * N * 8 * 2, dtype=torch.float64, device=DEV)
     if with_stats:
         d.stats = stats.data_ptr()
     L.call("mrisr_conv_forward", C.byref(d), stream())
     torch.cuda.synchronize()
-    return nchw(out), stats.cpu().view(N, 8, 2)
+    return nchw(out), stats.cpu().view(L.STAT_SLOTS, N, 8, 2).sum(0)
 
 
 def conv_wgrad(dt, srcs, dy_nchw, cout, cin, H, W, ks, combine=L.COMBINE_CONCAT, alpha=None):

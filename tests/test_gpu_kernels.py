@@ -162,12 +162,12 @@ def test_stem_forward_and_wgrad(dt):
     x, wt = torch.rand(n, 1, h, w, generator=torch.Generator().manual_seed(50)), rnd(cout, 1, 3, 3, seed=51)
     xd, wd = x.to(U.DEV).contiguous(), wt.reshape(cout, 9).contiguous().to(U.DEV)
     out = torch.empty((n, h, w, cout), dtype=U.tdt(dt), device=U.DEV)
-    stats = torch.zeros(n * 16, dtype=torch.float64, device=U.DEV)
+    stats = torch.zeros(L.STAT_SLOTS * n * 16, dtype=torch.float64, device=U.DEV)
     L.call("mrisr_stem_forward", dt, xd.data_ptr(), wd.data_ptr(), out.data_ptr(), stats.data_ptr(), n, h, w, cout, 8, U.stream())
     ref = F.conv2d(x, wt, padding=1)
     assert U.relerr(U.nchw(out), ref) <= TOL_OUT[dt]
     o = U.nchw(out).view(n, 8, cout // 8, h, w).double()
-    assert torch.allclose(stats.cpu().view(n, 8, 2)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    assert torch.allclose(stats.cpu().view(L.STAT_SLOTS, n, 8, 2).sum(0)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
     dy = rnd(n, cout, h, w, seed=52)
     dw = torch.zeros(cout * 9, dtype=torch.float32, device=U.DEV)
     L.call("mrisr_stem_wgrad", dt, xd.data_ptr(), U.nhwc(dy, dt).data_ptr(), dw.data_ptr(), n, h, w, cout, U.stream())
@@ -206,7 +206,9 @@ def _gn_forward_state(x, gamma, beta, dt):
     """Runs stats -> gn_finalize on the device for x (N,C,H,W); returns device tensors."""
     n, c, h, w = x.shape
     xr = U.rounded(x, dt).double().view(n, 8, -1)
-    stats = torch.stack([xr.sum(2), (xr * xr).sum(2)], -1).contiguous().to(U.DEV)
+    stats = torch.zeros(L.STAT_SLOTS, n, 8, 2, dtype=torch.float64)
+    stats[3] = torch.stack([xr.sum(2), (xr * xr).sum(2)], -1)          # any slot: gn_finalize adds them up
+    stats = stats.contiguous().to(U.DEV)
     scale, shift = torch.empty(n * c, device=U.DEV), torch.empty(n * c, device=U.DEV)
     mr = torch.empty(n * 16, device=U.DEV)
     gd, bd = gamma.to(U.DEV), beta.to(U.DEV)          # keep the device copies alive across the launch
@@ -302,13 +304,13 @@ def test_norm_pool2_and_upsample2(dt):
     assert U.relerr(U.nchw(out), ref) <= TOL_OUT[dt]
     # bilinear x2 + statistics, and its adjoint
     z = torch.empty((n, 2 * h, 2 * w, c), dtype=U.tdt(dt), device=U.DEV)
-    stats = torch.zeros(n * 16, dtype=torch.float64, device=U.DEV)
+    stats = torch.zeros(L.STAT_SLOTS * n * 16, dtype=torch.float64, device=U.DEV)
     L.call("mrisr_upsample2_stats", dt, xd.data_ptr(), z.data_ptr(), stats.data_ptr(), n, h, w, c, 8, U.stream())
     xr = U.rounded(x, dt).requires_grad_(True)
     up = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
     assert U.relerr(U.nchw(z), up.detach()) <= TOL_OUT[dt]
     o = up.detach().view(n, 8, c // 8, 2 * h, 2 * w).double()
-    assert torch.allclose(stats.cpu().view(n, 8, 2)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    assert torch.allclose(stats.cpu().view(L.STAT_SLOTS, n, 8, 2).sum(0)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
     dz = rnd(n, c, 2 * h, 2 * w, seed=87)
     up.backward(U.rounded(dz, dt))
     dzd = U.nhwc(dz, dt)

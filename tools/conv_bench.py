@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--filter", default="")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--raw", action="store_true", help="RAW source mode instead of NORM")
     a = ap.parse_args()
     dt = L.BF16 if a.dtype == "bf16" else L.F32
     tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
@@ -84,8 +86,11 @@ def main():
         wpf = torch.empty(L.load().mrisr_packed_weight_bytes(dt, cin, cout, ks), dtype=torch.uint8, device=dev)
         L.call("mrisr_pack_weights", dt, w.data_ptr(), cout, cin, ks, 1, wpf.data_ptr(), st)
         out = torch.empty(N, H, W, cout, device=dev, dtype=tdt)
-        stats = torch.zeros(N * 16, dtype=torch.float64, device=dev)
-        d.wpacked, d.out, d.stats = wp.data_ptr(), out.data_ptr(), stats.data_ptr()
+        stats = torch.zeros(L.STAT_SLOTS * N * 16, dtype=torch.float64, device=dev)
+        d.wpacked, d.out, d.stats = wp.data_ptr(), out.data_ptr(), (None if a.no_stats else stats.data_ptr())
+        if a.raw:
+            for i in range(nsrc):
+                d.src[i].mode = L.SRC_RAW
         dy = torch.randn(N, H, W, cout, device=dev).to(tdt)
         dd = L.ConvDesc()
         dd.dtype, dd.N, dd.H, dd.W, dd.Cin, dd.Cout, dd.ksize, dd.nsrc = dt, N, H, W, cout, cin, ks, 1
