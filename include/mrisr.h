@@ -95,6 +95,9 @@ size_t mrisr_packed_weight_bytes(int dtype, int Cout, int Cin, int ksize);
 int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, int ksize, int transpose_flip,
                        void* packed, void* stream);
 int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream);
+/* writes the name of the kernel instantiation mrisr_conv_forward (wgrad=0) / mrisr_conv_wgrad (wgrad=1) will
+ * launch for this descriptor, template arguments as in the mangled symbol rocprofv3 reports               */
+int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out, size_t n);
 /* weight gradient: dw[Cout][k][k][Cin] (fp32, ACCUMULATED) = sum_pix dy[pix][co] * in[pix+tap][ci];
  * the input is described exactly as in the forward desc (d->out, d->wpacked, d->bias ignored). */
 int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, void* stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "mrisr_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mrisr_pack_weights": (_i, [_i, _fp, _i, _i, _i, _i, _vp, _vp]),
     "mrisr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
+    "mrisr_conv_variant": (_i, [C.POINTER(ConvDesc), _i, C.c_char_p, _sz]),
     "mrisr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _fp, _vp]),
     "mrisr_stem_forward": (_i, [_i, _fp, _fp, _vp, _dp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_stem_wgrad": (_i, [_i, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
+                u32x2 packed[4];          // bf16 plain epilogue: the 4 quads of this fragment, packed
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = bn0 + ni * 32 + 8 * q + 4 * lh;      // first of 4 consecutive couts
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         v[j] = acc[ni][mi][4 * q + j];
                         acc[ni][mi][4 * q + j] = 0.f;
                     }
-                    if (pv && co < p.Cout) {
+                    const bool ok = pv && co < p.Cout;
+                    if (ok) {
                         if (p.bias) {
                             const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + co);
                             v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
@@ -322,23 +324,35 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         }
                         st_s[ni][q] += (v[0] + v[1]) + (v[2] + v[3]);
                         st_ss[ni][q] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                        if (!(p.dbg & 1)) {
-                            if constexpr (EPI == MRISR_OUT_PLAIN) {
-                                T* dst = outp + pix * p.Cout + co;
-                                if constexpr (sizeof(T) == 2) {
-                                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                                    *reinterpret_cast<bf16x4*>(dst) = pk;
-                                } else {
-                                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                                }
-                            } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
-                                const int C4 = p.Cout >> 2, c4 = co >> 2;
+                    }
+                    if constexpr (EPI == MRISR_OUT_PLAIN && sizeof(T) == 2) {
+                        union { bf16x4 b; u32x2 u; } cv;
+                        cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        packed[q] = cv.u;
+                    } else if (ok && !(p.dbg & 1)) {
+                        if constexpr (EPI == MRISR_OUT_PLAIN) {
+                            *reinterpret_cast<f32x4*>(outp + pix * p.Cout + co) = f32x4{v[0], v[1], v[2], v[3]};
+                        } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
+                            const int C4 = p.Cout >> 2, c4 = co >> 2;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    outp[((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4] =
-                                        from_f32<T>(v[j]);
-                            }
+                            for (int j = 0; j < 4; ++j)
+                                outp[((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4] =
+                                    from_f32<T>(v[j]);
                         }
+                    }
+                }
+                if constexpr (EPI == MRISR_OUT_PLAIN && sizeof(T) == 2) {
+                    // lanes l and l+32 hold the two 4-channel halves of each 8-channel group of the same pixel:
+                    // exchange so that every lane owns 8 consecutive channels -> 16-byte stores (half the store
+                    // instructions).  Quad pair (q, q+1): low half keeps group q, high half keeps group q+1.
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        u32x2 a = packed[q], b = packed[q + 1];
+                        auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        const int co8 = bn0 + ni * 32 + 8 * (q + lh);      // first of the 8 channels this lane now owns
+                        if (pv && co8 < p.Cout && !(p.dbg & 1)) *reinterpret_cast<u32x4*>(outp + pix * p.Cout + co8) = o;
                     }
                 }
             }
@@ -599,6 +613,27 @@ static int dispatch_conv_sp(ConvParams& p, int spatial, int ks, hipStream_t s) {
     if (spatial == MRISR_SP_NONE) return launch_conv<T, BN, MRISR_SP_NONE, 1>(p, s);
     if (spatial == MRISR_SP_UP2) return launch_conv<T, BN, MRISR_SP_UP2, 1>(p, s);
     MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: 1x1 conv with pooled source");
+}
+
+// Name of the template instantiation the dispatcher picks for a descriptor (the grouping rocprofv3 reports).
+extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out, size_t n) {
+    ConvParams p;
+    int rc = conv_fill_params(d, p, "conv_variant");
+    if (rc) return rc;
+    if (!out || n < 8) MRISR_FAIL(MRISR_E_ARG, "conv_variant: bad buffer");
+    const char* t = d->dtype == MRISR_BF16 ? "bf16" : "f32";
+    const int loader = d->combine == MRISR_COMBINE_BLEND ? 3 : d->src[0].spatial;
+    if (wgrad) {
+        snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d>", t, loader, d->ksize);
+    } else {
+        const int BN = conv_choose_bn(d->Cout), pad = d->ksize / 2, TW = 1 << p.tw_log2;
+        const size_t halo = (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * kHaloRowBytes;
+        const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
+        const int ws = (p.nchunks * wimg + 2 * halo <= 150 * 1024) ? 1 : 0;
+        snprintf(out, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", t, BN, loader, d->ksize, ws,
+                 d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 ? 1 : 0);
+    }
+    return MRISR_OK;
 }
 
 extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {

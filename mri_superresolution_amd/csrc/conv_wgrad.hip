@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     // channel vector of this thread inside the conv input for the halo: sub-chunk (ch8>>2), chunk (ch8&3)
     const int c_in = ci0 + ch8 * VEC;
     auto issue = [&](int n, int ty0, int tx0) {
+        if (p.dbg & 4) return;
         const int c = co0 + ch8 * VEC;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         }
     };
     auto commit = [&](char* buf, int n) {
+        if (p.dbg & 2) return;
         char* lds_dy = buf;
         char* lds_in = buf + 256 * 128;
 #pragma unroll
@@ -209,13 +211,14 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         }
         const char* lds_dy = smem + cur * buf_bytes;
         const char* lds_in = lds_dy + 256 * 128;
-        if constexpr (kBf16) {
+        if (p.dbg & 8) {
+        } else if constexpr (kBf16) {
             const int li = lane & 15, gq = li >> 2, gp = li & 3, gr = (lane >> 4) & 1;
             const int chb = 16 * gr + 4 * gp;            // channel inside the 32-wide fragment
             const int c_dy = fo * 32 + chb, c_b = fi * 32 + chb;
             // 1x1: both groups take the single tap and split the k-steps
             const int ks_lo = (NTAPS == 1 ? 8 * tg : 0) + kpart, ks_hi = NTAPS == 1 ? 8 * tg + 8 : 16;
-#pragma unroll 1
+#pragma unroll 2
             for (int ks = ks_lo; ks < ks_hi; ks += kparts) {
                 const int pk = ks * 16 + 8 * lh + gq;    // pixel (second read: +4)
                 const bf16x8 af = tr_read_frag(
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
 
     // ---- accumulate into dW[co][tap][ci]: lane = ci (128-B contiguous per half wave), regs = co
     const int ci = ci0 + fi * 32 + lr;
-    if (ci < p.Cin) {
+    if (ci < p.Cin && !(p.dbg & 1)) {
 #pragma unroll
         for (int j = 0; j < NT0; ++j) {
             const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);

@@ -9,12 +9,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                                                        T* __restrict__ out, double* __restrict__ stats, int H, int W,
                                                        int Cout, int groups, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    extern __shared__ float sm[];            // [Cout*9] weights, then [groups*2] statistics
-    float* sw = sm;
-    float* sst = sm + Cout * 9;
+    extern __shared__ double smd[];          // [groups*2] statistics (fp64: the order of the LDS atomics must not
+    double* sst = smd;                       //  perturb mean / rstd - a 1e-7 wobble flips LeakyReLU signs run to run)
+    float* sw = reinterpret_cast<float*>(smd + 2 * (groups > 0 ? groups : 1));     // then [Cout*9] weights
     const int t = threadIdx.x, n = blockIdx.y;
     for (int i = t; i < Cout * 9; i += 256) sw[i] = w[i];
-    for (int i = t; i < groups * 2; i += 256) sst[i] = 0.f;
+    for (int i = t; i < groups * 2; i += 256) sst[i] = 0.0;
     __syncthreads();
     const int nvec = Cout / VEC, ppb = 256 / nvec;
     const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         if (pl < ppb) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                atomicAdd(&sst[2 * ((c + e) / gs)], s[e]);
-                atomicAdd(&sst[2 * ((c + e) / gs) + 1], ss[e]);
+                atomicAdd(&sst[2 * ((c + e) / gs)], (double)s[e]);
+                atomicAdd(&sst[2 * ((c + e) / gs) + 1], (double)ss[e]);
             }
         }
         __syncthreads();
         for (int i = t; i < groups * 2; i += 256)
-            atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], (double)sst[i]);
+            atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], sst[i]);
     }
 }
 
@@ -70,7 +70,7 @@ extern "C" int mrisr_stem_forward(int dtype, const float* x, const float* w, voi
     const int ppb = 256 / (Cout / vec);
     int ppblk = ppb * 64;
     dim3 grid(ceil_div(H * W, ppblk), N);
-    const size_t lds = (size_t)(Cout * 9 + (groups > 0 ? groups : 0) * 2) * sizeof(float);
+    const size_t lds = (size_t)Cout * 9 * sizeof(float) + (size_t)(groups > 0 ? groups : 1) * 2 * sizeof(double);
     if (dtype == MRISR_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, H, W, Cout, groups, ppblk);
     else if (dtype == MRISR_F32) stem_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (float*)out, stats, H, W, Cout, groups, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "stem_forward: dtype %d", dtype);

@@ -453,10 +453,10 @@ extern "C" int mrisr_channel_sum(int dtype, const void* x, float* out, size_t np
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int HW,
                                                        int C, int groups, int pix_per_block) {
-    __shared__ float lds[64 * 2];
+    __shared__ double lds[64 * 2];           // fp64: order-independent to ~1e-16
     const int t = threadIdx.x, n = blockIdx.y;
     const int gs = C / groups;
-    for (int i = t; i < groups * 2; i += 256) lds[i] = 0.f;
+    for (int i = t; i < groups * 2; i += 256) lds[i] = 0.0;
     __syncthreads();
     const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
     const T* xb = x + (size_t)n * HW * C;
@@ -468,12 +468,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
             s += v;
             ss += v * v;
         }
-        atomicAdd(&lds[2 * (c / gs)], s);
-        atomicAdd(&lds[2 * (c / gs) + 1], ss);
+        atomicAdd(&lds[2 * (c / gs)], (double)s);
+        atomicAdd(&lds[2 * (c / gs) + 1], (double)ss);
     }
     __syncthreads();
     for (int i = t; i < groups * 2; i += 256)
-        atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], (double)lds[i]);
+        atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], lds[i]);
 }
 
 int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s) {
@@ -543,13 +543,13 @@ __global__ __launch_bounds__(256) void upsample2_stats_kernel(const T* __restric
                                                               double* __restrict__ stats, int h, int w, int C,
                                                               int groups, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    __shared__ float lds[64 * 2];
+    __shared__ double lds[64 * 2];
     const int t = threadIdx.x, n = blockIdx.y;
     const int nvec = C / VEC, ppb = 256 / nvec;
     const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
     const int H = 2 * h, W = 2 * w, HW = H * W;
     const int gs = C / groups;
-    for (int i = t; i < groups * 2; i += 256) lds[i] = 0.f;
+    for (int i = t; i < groups * 2; i += 256) lds[i] = 0.0;
     __syncthreads();
     float s[VEC], ss[VEC];
 #pragma unroll
@@ -580,13 +580,13 @@ __global__ __launch_bounds__(256) void upsample2_stats_kernel(const T* __restric
         if (pl < ppb) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                atomicAdd(&lds[2 * ((c + e) / gs)], s[e]);
-                atomicAdd(&lds[2 * ((c + e) / gs) + 1], ss[e]);
+                atomicAdd(&lds[2 * ((c + e) / gs)], (double)s[e]);
+                atomicAdd(&lds[2 * ((c + e) / gs) + 1], (double)ss[e]);
             }
         }
         __syncthreads();
         for (int i = t; i < groups * 2; i += 256)
-            atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], (double)lds[i]);
+            atomic_add_f64(&stats[stat_slot_off(gridDim.y, groups) + (size_t)n * groups * 2 + i], lds[i]);
     }
 }
 

@@ -108,14 +108,6 @@ class KernelTimer:
                 for k, (n, fl, ms) in agg.items()}
 
 
-def conv_kernel_name(kind: str, dt: int, cout: int, spatial: int, ks: int) -> str:
-    """Mirrors the dispatch in csrc/conv_fwd.hip / conv_wgrad.hip."""
-    t = "bf16" if dt == L.BF16 else "f32"
-    if kind == "wgrad":
-        return f"conv_wgrad_kernel<{t},SP{spatial},K{ks}>"
-    return f"conv_igemm_kernel<{t},BN{64 if cout >= 64 else 32},SP{spatial},K{ks}>"
-
-
 class UNetEngine:
     """Executes UNetSuperRes on one GPU.  ``params``: dict key -> fp32 tensor (conv weights in
     channels_last storage, i.e. physically [Cout][kh][kw][Cin]); ``grads``: same keys."""
@@ -172,11 +164,13 @@ class UNetEngine:
         self._pack_versions: Dict[tuple, int] = {}
         self.timer: Optional[KernelTimer] = None
 
-    def _launch(self, kind, dt, N, H, W, cin, cout, spatial, ks, fn):
+    def _launch(self, kind, desc, fn):
         if self.timer is None:
             return fn()
-        flops = 2.0 * N * H * W * cin * cout * ks * ks
-        self.timer.launch(conv_kernel_name(kind, dt, cout, spatial, ks), flops, fn)
+        flops = 2.0 * desc.N * desc.H * desc.W * desc.Cin * desc.Cout * desc.ksize * desc.ksize
+        buf = C.create_string_buffer(96)
+        L.call("mrisr_conv_variant", C.byref(desc), 1 if kind == "wgrad" else 0, buf, 96)
+        self.timer.launch(buf.value.decode(), flops, fn)
 
     # ------------------------------------------------------------------ weights
     def _packed_weight(self, layer: Layer, params, dt: int, flip: int, stream, force: bool = False):
@@ -300,8 +294,7 @@ class UNetEngine:
                 d.out, d.stats = zlow.data_ptr(), None
             else:
                 d.out, d.stats = o.raw.data_ptr(), o.stats.data_ptr()
-            self._launch("fwd", dt, N, vh, vw, layer.cin, layer.cout, layer.srcs[0].spatial, layer.ks,
-                         lambda: L.call("mrisr_conv_forward", C.byref(d), st))
+            self._launch("fwd", d, lambda: L.call("mrisr_conv_forward", C.byref(d), st))
             if layer.post_up:
                 L.call("mrisr_upsample2_stats", dt, zlow.data_ptr(), o.raw.data_ptr(), o.stats.data_ptr(),
                        N, vh, vw, o.C, GN_GROUPS, st)
@@ -391,9 +384,8 @@ class UNetEngine:
                 L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st)
                 dy = dyl
             d = self._desc(layer, dt, N, params)
-            self._launch("wgrad", dt, N, layer.H, layer.W, layer.cin, layer.cout, layer.srcs[0].spatial, layer.ks,
-                         lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
-                                        grads[layer.name + ".weight"].data_ptr(), st))
+            self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
+                                                    grads[layer.name + ".weight"].data_ptr(), st))
             if layer.bias:
                 L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
                        N * layer.H * layer.W, layer.cout, st)
@@ -408,8 +400,7 @@ class UNetEngine:
             dd.wpacked = self._packed_weight(layer, params, dt, 1, st, force=True).data_ptr()
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
-            self._launch("dgrad", dt, N, layer.H, layer.W, layer.cout, layer.cin, L.SP_NONE, layer.ks,
-                         lambda: L.call("mrisr_conv_forward", C.byref(dd), st))
+            self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))
             if layer.combine == L.COMBINE_BLEND:
                 a, b = layer.srcs[0].node, layer.srcs[1].node
                 L.call("mrisr_blend_alpha_grad", dt, dain.data_ptr(), a.raw.data_ptr(), a.scale.data_ptr(),

@@ -95,7 +95,7 @@ def test_loss_and_gradients_fp32(golden_dir, case, ssim_weight):
         r = ref_grads[k]
         err = (p.grad.cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-7)
         worst = max(worst, err)
-        assert err <= 2e-3, f"{k}: rel err {err:.3e}"
+        assert err <= 5e-4, f"{k}: rel err {err:.3e}"
     _report(f"grads fp32 {case} ssim_w={ssim_weight}: loss err {abs(loss.item() - float(ref_loss)):.2e}, worst grad rel err {worst:.2e}")
 
 
@@ -153,13 +153,13 @@ def test_loss_api_errors_and_edges():
     assert abs(ident - 1.0) <= 1e-6
 
 
-@pytest.mark.parametrize("name,tols", [("train3_l1", (2e-6, 2e-5, 2e-4)), ("train3", (2e-6, 2e-4, 2e-3))])
+@pytest.mark.parametrize("name,tols", [("train3_l1", (2e-6, 2e-5, 2e-4)), ("train3", (2e-6, 2e-5, 2e-4))])
 def test_train3_matches_reference_golden(golden_dir, name, tols):
     """Three optimiser steps in the order of scripts/train.py:301-323 against the reference's own loss
-    sequence.  Adam's first steps move every weight by ~lr*sign(g), so gradient noise at the fp32
-    summation-order level flips signs of near-zero entries and the trajectories drift apart; the SSIM
-    term adds its sigma = E[x^2]-mu^2 cancellation noise (measured on the CPU oracle: 1e-4 relative
-    gradient noise -> 2e-4 loss drift at step 3), hence the wider tolerance for the SSIM run."""
+    sequence.  Adam's first steps move every weight by ~lr*sign(g), so fp32 summation-order noise in the
+    gradients flips signs of near-zero entries and the trajectories drift slightly (measured: <= 2e-5 at
+    step 3 once the GroupNorm statistics are accumulated in fp64; with fp32 LDS atomics a 1e-7 wobble of
+    mean/rstd flipped a LeakyReLU sign run to run and the drift was 40x larger)."""
     g = _golden(golden_dir, name)
     f, n, h, w, seed = (int(v) for v in g["meta"])
     m = _model(f, seed, torch.float32).train()
