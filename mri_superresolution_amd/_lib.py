@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrisr.so")
+LIB_PATH = os.environ.get("MRISR_LIB") or os.path.join(_HERE, "libmrisr.so")   # MRISR_LIB: A/B builds (tuning)
 
 F32, BF16 = 0, 1
 SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
@@ -82,6 +82,8 @@ def load():
             "`python -m mri_superresolution_amd.build` (needs hipcc); there is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("MRISR_LIB") and not hasattr(lib, name):
+            continue                  # A/B build of an older revision (tuning only)
         fn = getattr(lib, name)       # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Folds two rocprofv3 PMC passes (one `--pmc FETCH_SIZE`, one `--pmc WRITE_SIZE`, each with --kernel-trace only)
+into profiles/pmc_traffic.json: HBM bytes per launch, per kernel symbol.
+
+Corrections (MI355X_MICROARCH.md, 'HBM'): both counters are in KiB-free units of... see below; on gfx950 FETCH_SIZE
+reports exactly half of the bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane
+stores and dword float atomics.  Both counters come from the L2's memory-side request counters (Infinity-Cache hits
+are counted, not excluded), i.e. this is traffic leaving L2, an upper bound on DRAM traffic.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def demangle_conv(name):
+    m = re.match(r"_Z17conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)EEv10ConvParams", name)
+    if m:
+        t = "bf16" if m.group(1) == "DF16b" else "f32"
+        return f"conv_igemm_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}>"
+    m = re.match(r"_Z17conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)EEv10ConvParams", name)
+    if m:
+        t = "bf16" if m.group(1) == "DF16b" else "f32"
+        return f"conv_wgrad_kernel<{t},{m.group(2)},{m.group(3)}>"
+    return re.sub(r"\(.*", "", name)
+
+
+def rows(path, counter):
+    """(kernel name, counter value) per dispatch from a rocprofv3 counter_collection CSV or a rocpd .db."""
+    if path.endswith(".db"):
+        import sqlite3
+        db = sqlite3.connect(path)
+        yield from db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,))
+    else:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == counter:
+                    yield r["Kernel_Name"], r["Counter_Value"]
+
+
+def collect(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for name, val in rows(path, counter):
+        k = demangle_conv(name)
+        tot[k] += float(val)
+        cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    fetch_csv, write_csv = sys.argv[1], sys.argv[2]
+    out = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+    ft, fc = collect(fetch_csv, "FETCH_SIZE")
+    wt, wc = collect(write_csv, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(ft) | set(wt)):
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 B)
+        rd = 2.0 * ft.get(k, 0.0) * 1024 / max(fc.get(k, 1), 1)
+        wr = wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)
+        kernels[k] = {"launches": fc.get(k, wc.get(k, 0)), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                      "hbm_bytes_per_launch": round(rd + wr)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), "
+                         "FETCH_SIZE x2 (gfx950 wide-read correction), KB->bytes x1024",
+               "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:25]:
+        print(f"{k[:70]:70s} n={v['launches']:4d} rd {v['read_bytes_per_launch'] / 1e6:9.2f} MB  wr {v['write_bytes_per_launch'] / 1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
