@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--base-filters", type=int, default=64)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--ssim-weight", type=float, default=0.4)
+    ap.add_argument("--perceptual-weight", type=float, default=0.0,
+                    help="BASELINE.json configs[2]: + VGG19 perceptual term (random-init VGG19: no weights offline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="eval forward only (inference metric; not the headline)")
@@ -105,7 +107,15 @@ def main():
     torch.manual_seed(0)
     model = UNetSuperRes(1, 1, args.base_filters).to(dev).set_compute_dtype(dtype).train()
     opt = FusedAdam(model, lr=1e-4, weight_decay=1e-5)
-    crit = CombinedLoss(ssim_weight=args.ssim_weight, device=dev)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # random-init VGG19 announcement (stated in `data` below)
+        crit = CombinedLoss(ssim_weight=args.ssim_weight, perceptual_weight=args.perceptual_weight, device=dev)
+    vgg_eng = None
+    if args.perceptual_weight > 0:
+        crit = crit.to(dev)
+        fe = crit.perceptual_loss.feature_extractor.set_compute_dtype(dtype)
+        vgg_eng = fe._engine
     metric = SSIM(device=dev)
     dp = None
     if world > 1:
@@ -162,6 +172,8 @@ def main():
     timed_steps = 0
     if not args.no_kernel_timer:            # every rank steps (the step holds collectives); rank 0 reports
         timer = model._engine.timer = KernelTimer()
+        if vgg_eng is not None:
+            vgg_eng.timer = timer
         timed_steps = min(args.steps, 10)
         t1 = time.perf_counter()
         for _ in range(timed_steps):
@@ -169,6 +181,8 @@ def main():
         torch.cuda.synchronize()
         timed_elapsed = time.perf_counter() - t1
         model._engine.timer = None
+        if vgg_eng is not None:
+            vgg_eng.timer = None
     if world > 1:
         dist.barrier()
 
@@ -177,13 +191,17 @@ def main():
         value = world * B * args.steps / elapsed
         f_fwd = unet_flops_fwd(args.base_filters, S, S)
         flops_slice = f_fwd if args.forward_only else 3.0 * f_fwd
+        perc = args.perceptual_weight > 0 and not args.forward_only
+        if perc:      # VGG19 features[:36] at the 2Sx2S output: 777,600 FLOP/pixel forward; gen + target + dgrad
+            flops_slice += 3.0 * 777600.0 * (2 * S) * (2 * S)
         rec = {
             "metric": METRIC if not args.forward_only else "2D MRI slices/sec (eval forward) 256×256 U-Net",
             "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"UNetSuperRes base_filters={args.base_filters} depth=4, {S}x{S} slices -> {2 * S}x{2 * S}, "
-                                   f"batch={B}/GPU {args.dtype}, L1+SSIM({args.ssim_weight}), "
+                                   f"batch={B}/GPU {args.dtype}, L1+SSIM({args.ssim_weight})"
+                                   + (f"+VGG19-perceptual({args.perceptual_weight}, relu5_4, L1, random-init weights), " if perc else ", ")
                                    + ("eval forward" if args.forward_only else "train step fwd+bwd+Adam+SSIM metric"),
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "conv_flops_per_slice": flops_slice,

@@ -81,6 +81,9 @@ typedef struct {
     const float* bias;      /* [Cout] or NULL                                                  */
     void* out;              /* NHWC [N][H][W][Cout] (or pixel-shuffled [N][2H][2W][Cout/4])    */
     double* stats;          /* [MRISR_STAT_SLOTS][N][groups][2] (sum, sum of squares), accumulated; or NULL */
+    const void* relu_mask;  /* NULL, or a tensor shaped like out: out is zeroed where relu_mask <= 0 (the ReLU
+                               backward of the frozen VGG19 stack, utils/losses.py:95,145: this conv computes
+                               dL/d(relu output), relu_mask = that relu output); 3x3, plain source/output only */
 } mrisr_conv_desc;
 
 const char* mrisr_last_error(void);
@@ -190,6 +193,28 @@ int mrisr_ssim_l1_backward(const float* a, const float* b, const float* coef, co
  * ssim_w*(1-clamp(SSIM,0,1)), out[1] = L1 mean, out[2] = SSIM mean, out[3+n] = per-sample SSIM.   */
 int mrisr_loss_finalize(const double* sums, int N, int H, int W, float l1_w, float ssim_w, float* out,
                         void* stream);
+
+/* ---- perceptual loss: glue of the frozen VGG19 feature stack (utils/losses.py:83-151).  The 3x3 convolutions are
+ *      mrisr_conv_forward calls (bias + relu_out forward; relu_mask for the input gradient). ------------------- */
+/* channels of the normalised VGG input tensor (3 real + zero padding to one 16-byte bf16 vector) */
+int mrisr_vgg_input_channels(void);
+/* x [npix] fp32 gray -> out [npix][8] (dtype): repeat(1,3,1,1) + (x-mean)/std (losses.py:105-114), channels 3..7 = 0 */
+int mrisr_vgg_input_forward(int dtype, const float* x, void* out, size_t npix, void* stream);
+/* adjoint: dimg[npix] (fp32, ACCUMULATED) += gscale[0]*scale * sum_c dx3[npix][c]/std_c  (gscale: device scalar or NULL) */
+int mrisr_vgg_input_backward(int dtype, const void* dx3, const float* gscale, float scale, float* dimg,
+                             size_t npix, void* stream);
+/* nn.MaxPool2d(2) on NHWC: out [N][H/2][W/2][C] */
+int mrisr_maxpool2_forward(int dtype, const void* x, void* out, int N, int H, int W, int C, void* stream);
+/* its adjoint (first maximum wins, as aten): dx [N][H][W][C] from dy [N][H/2][W/2][C]; relu_gate=1 also zeroes dx
+ * where x <= 0 (x is then the output of the nn.ReLU in front of the pool: ReLU backward fused)                  */
+int mrisr_maxpool2_backward(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                            int relu_gate, void* stream);
+/* nn.L1Loss (kind 0) / nn.MSELoss (kind 1) between two feature tensors of n elements (losses.py:127-131,150):
+ * out[0] = mean; sum16 = 16 doubles of scratch; da (optional, dtype) receives the UNSCALED gradient sign(a-b) or
+ * 2(a-b) (times [a>0] when relu_gate=1: a is a ReLU output) - the 1/n and the upstream gradient are applied by
+ * mrisr_vgg_input_backward at the end of the (linear) input-gradient chain.                                      */
+int mrisr_feature_loss(int dtype, const void* a, const void* b, size_t n, int kind, double* sum16, float* out,
+                       void* da, int relu_gate, void* stream);
 
 /* ---- optimiser: torch.optim.Adam with L2-coupled weight decay (scripts/train.py:186) ------- */
 /* grad_scale multiplies g first (1/world_size after a sum all-reduce).                        */

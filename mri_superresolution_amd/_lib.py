@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("ksize", C.c_int32), ("nsrc", C.c_int32),
                 ("combine", C.c_int32), ("out_mode", C.c_int32), ("groups", C.c_int32),
                 ("relu_out", C.c_int32), ("src", Src * 2), ("blend_alpha", _fp), ("wpacked", _vp),
-                ("bias", _fp), ("out", _vp), ("stats", _dp)]
+                ("bias", _fp), ("out", _vp), ("stats", _dp), ("relu_mask", _vp)]
 
 
 class Consumer(C.Structure):
@@ -64,6 +64,12 @@ SIGNATURES = {
     "mrisr_ssim_l1_forward": (_i, [_fp, _fp, _dp, _fp, _i, _i, _i, _f, _f, _vp]),
     "mrisr_ssim_l1_backward": (_i, [_fp, _fp, _fp, _dp, _fp, _f, _f, _fp, _i, _i, _i, _f, _vp]),
     "mrisr_loss_finalize": (_i, [_dp, _i, _i, _i, _f, _f, _fp, _vp]),
+    "mrisr_vgg_input_channels": (_i, []),
+    "mrisr_vgg_input_forward": (_i, [_i, _fp, _vp, _sz, _vp]),
+    "mrisr_vgg_input_backward": (_i, [_i, _vp, _fp, _f, _fp, _sz, _vp]),
+    "mrisr_maxpool2_forward": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mrisr_maxpool2_backward": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_feature_loss": (_i, [_i, _vp, _vp, _sz, _i, _dp, _fp, _vp, _i, _vp]),
     "mrisr_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "mrisr_cast": (_i, [_i, _vp, _i, _vp, _sz, _vp]),
 }

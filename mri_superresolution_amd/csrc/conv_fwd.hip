@@ -47,6 +47,7 @@ struct Prefetch {
 
 constexpr int kFwdThreads = 512;    // two 4-wave halves working in antiphase
 constexpr int kLoaderBlend = 3;     // template-only loader kind: sigmoid(alpha)-blend of two sources
+constexpr int kEpiMask = 2;         // template-only epilogue kind: plain store gated by relu_mask > 0 (VGG dgrad)
 
 // Work decomposition: a persistent 8-wave workgroup owns one cout block (BN channels) and a contiguous range
 // of 256-pixel tiles.  Its two halves (waves 0-3 / 4-7) each walk their own tiles; a work item is (tile, cin
@@ -325,12 +326,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         st_s[ni][q] += (v[0] + v[1]) + (v[2] + v[3]);
                         st_ss[ni][q] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                     }
-                    if constexpr (EPI == MRISR_OUT_PLAIN && sizeof(T) == 2) {
+                    if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
                         union { bf16x4 b; u32x2 u; } cv;
                         cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         packed[q] = cv.u;
                     } else if (ok && !(p.dbg & 1)) {
-                        if constexpr (EPI == MRISR_OUT_PLAIN) {
+                        if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2) {
+                            if constexpr (EPI == kEpiMask) {   // ReLU backward: keep the gradient where the activation is > 0
+                                const f32x4 m = *reinterpret_cast<const f32x4*>((const float*)p.mask + pix * p.Cout + co);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
+                            }
                             *reinterpret_cast<f32x4*>(outp + pix * p.Cout + co) = f32x4{v[0], v[1], v[2], v[3]};
                         } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
                             const int C4 = p.Cout >> 2, c4 = co >> 2;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         }
                     }
                 }
-                if constexpr (EPI == MRISR_OUT_PLAIN && sizeof(T) == 2) {
+                if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
                     // lanes l and l+32 hold the two 4-channel halves of each 8-channel group of the same pixel:
                     // exchange so that every lane owns 8 consecutive channels -> 16-byte stores (half the store
                     // instructions).  Quad pair (q, q+1): low half keeps group q, high half keeps group q+1.
@@ -350,9 +356,20 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         u32x2 a = packed[q], b = packed[q + 1];
                         auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                         auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
                         const int co8 = bn0 + ni * 32 + 8 * (q + lh);      // first of the 8 channels this lane now owns
-                        if (pv && co8 < p.Cout && !(p.dbg & 1)) *reinterpret_cast<u32x4*>(outp + pix * p.Cout + co8) = o;
+                        if (pv && co8 < p.Cout && !(p.dbg & 1)) {
+                            if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
+                                const u32x4 m = *reinterpret_cast<const u32x4*>((const T*)p.mask + pix * p.Cout + co8);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const unsigned lo = __uint_as_float(m[k] << 16) > 0.f ? 0x0000ffffu : 0u;
+                                    const unsigned hi = __uint_as_float(m[k] & 0xffff0000u) > 0.f ? 0xffff0000u : 0u;
+                                    o[k] &= (lo | hi);
+                                }
+                            }
+                            *reinterpret_cast<u32x4*>(outp + pix * p.Cout + co8) = o;
+                        }
                     }
                 }
             }
@@ -524,6 +541,7 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
     if (csum != d->Cin) MRISR_FAIL(MRISR_E_SHAPE, "%s: sources carry %d channels, Cin=%d", who, csum, d->Cin);
     const int BK = conv_bk(d->dtype), BN = conv_choose_bn(d->Cout);
     p.blend_alpha = d->blend_alpha; p.wpacked = d->wpacked; p.bias = d->bias; p.out = d->out; p.stats = d->stats;
+    p.mask = d->relu_mask;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
     p.nchunks = ceil_div(d->Cin, BK); p.CinP = p.nchunks * BK;
     p.ncb = ceil_div(d->Cout, BN); p.CoutP = p.ncb * BN;
@@ -576,6 +594,8 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
         if constexpr (kPS) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         attr_set = true;
     }
@@ -585,6 +605,13 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
             else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1>), dim3(grid), dim3(kFwdThreads), lds, s, p);
         } else {
             MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: pixel-shuffle epilogue needs a 3x3 conv with a plain source");
+        }
+    } else if (p.mask) {
+        if constexpr (kPS) {
+            if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+        } else {
+            MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask epilogue needs a 3x3 conv with a plain source");
         }
     } else if (p.ws) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0>), dim3(grid), dim3(kFwdThreads), lds, s, p);
@@ -631,7 +658,7 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
         const int ws = (p.nchunks * wimg + 2 * halo <= 150 * 1024) ? 1 : 0;
         snprintf(out, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", t, BN, loader, d->ksize, ws,
-                 d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 ? 1 : 0);
+                 d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 ? 1 : (d->relu_mask ? kEpiMask : 0));
     }
     return MRISR_OK;
 }
@@ -642,6 +669,8 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     if (rc) return rc;
     if (!d->wpacked || !d->out) MRISR_FAIL(MRISR_E_ARG, "conv_forward: null weights/out");
     if (d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (d->Cout % 4)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: pixel shuffle needs Cout%%4==0");
+    if (d->relu_mask && (d->out_mode != MRISR_OUT_PLAIN || d->Cout % (d->dtype == MRISR_BF16 ? 8 : 4)))
+        MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask needs a plain output with Cout a multiple of the 16-byte vector");
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);
     const int sp = d->src[0].spatial;
     hipStream_t s = (hipStream_t)stream;

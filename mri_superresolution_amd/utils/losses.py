@@ -102,25 +102,70 @@ def ssim(img1, img2, window_size=11, sigma=1.5, val_range=1.0, device=None, wind
 
 
 class VGGFeatureExtractor(nn.Module):
-    """Reference losses.py:83-118 builds torchvision's pretrained VGG19 here.  torchvision and its
-    ImageNet weights are not available offline in this build; the HIP conv kernels
-    can run the VGG19 feature stack, but it is not wired up in this round."""
+    """VGG19 ``features[:feature_layer_idx+1]`` on frozen weights, input = gray image replicated to 3 channels and
+    ImageNet-normalised (reference losses.py:83-118).  Runs on libmrisr kernels (``mri_superresolution_amd.vgg``).
 
-    def __init__(self, feature_layer_idx=35, use_maxpool=False):
+    The reference downloads torchvision's ``VGG19_Weights.IMAGENET1K_V1``; offline that is impossible, so weights
+    come from a LOCAL torchvision-format file (``weights_path`` or env ``MRISR_VGG19_WEIGHTS``) or, failing that,
+    from a Kaiming initialisation (a warning is issued: loss values are then not comparable with the reference's).
+    ``state_dict`` keys match the reference module (``features.N.weight/bias``, buffers ``mean``/``std``).
+    ``forward`` is an inference call (no autograd graph); ``PerceptualLoss`` differentiates through the stack."""
+
+    def __init__(self, feature_layer_idx=35, use_maxpool=False, weights_path=None, compute_dtype=torch.bfloat16):
         super().__init__()
-        raise NotImplementedError(
-            "VGG19 perceptual features are not available in this build: torchvision / ImageNet weights "
-            "are absent offline (perceptual_weight must be 0)")
+        from ..vgg import VGGEngine, build_feature_modules, default_weights_path, load_local_vgg19_weights
+        self.feature_layer_idx = feature_layer_idx
+        self.features = build_feature_modules(feature_layer_idx)
+        path = weights_path or default_weights_path()
+        if path:
+            load_local_vgg19_weights(self.features, path)
+            self.pretrained = True
+        else:
+            import warnings
+            for m in self.features:
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                    nn.init.zeros_(m.bias)
+            self.pretrained = False
+            warnings.warn("VGG19 ImageNet weights are not available offline: the perceptual feature extractor is "
+                          "randomly initialised (set MRISR_VGG19_WEIGHTS to a local torchvision vgg19 state_dict)")
+        for p in self.features.parameters():
+            p.requires_grad = False
+        self.register_buffer("mean", torch.tensor(VGG_MEAN).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor(VGG_STD).view(1, 3, 1, 1))
+        self.compute_dtype = compute_dtype
+        self._engine = VGGEngine(self.features)
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+        return self
+
+    def forward(self, x):
+        feat, _ = self._engine.forward(x, self.compute_dtype, save=False)
+        return feat.permute(0, 3, 1, 2).to(torch.float32)
 
 
 class PerceptualLoss(nn.Module):
-    """Reference losses.py:120-151."""
+    """L1 or MSE between VGG19 features of the generated and the (detached) target image
+    (reference losses.py:120-151)."""
 
-    def __init__(self, feature_layer_idx=35, loss_type="l1"):
+    def __init__(self, feature_layer_idx=35, loss_type="l1", weights_path=None, compute_dtype=torch.bfloat16):
         super().__init__()
-        if loss_type not in ("l1", "l2", "mse"):
+        if loss_type == "l1":
+            self.kind = 0
+        elif loss_type in ("l2", "mse"):
+            self.kind = 1
+        else:
             raise ValueError(f"Unsupported loss type for PerceptualLoss: {loss_type}")
-        self.feature_extractor = VGGFeatureExtractor(feature_layer_idx=feature_layer_idx)
+        self.feature_extractor = VGGFeatureExtractor(feature_layer_idx=feature_layer_idx, weights_path=weights_path,
+                                                     compute_dtype=compute_dtype)
+        self.feature_extractor.eval()
+
+    def forward(self, generated, target):
+        from ..vgg import _PerceptualFn
+        if target.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("gradient w.r.t. the perceptual target is not implemented (the reference detaches it)")
+        return _PerceptualFn.apply(generated, target, self.feature_extractor, self.kind)
 
 
 class CombinedLoss(nn.Module):
@@ -149,13 +194,21 @@ class CombinedLoss(nn.Module):
         self.perceptual_loss = (PerceptualLoss(feature_layer_idx=vgg_layer_idx, loss_type=perceptual_loss_type)
                                 if self.use_perceptual else None)
         self.last_components = None
+        self.last_perceptual = None
 
     def forward(self, output, target):
         l1_w = self.l1_weight if self.l1_weight > 0 else 0.0
         s_w = self.ssim_weight if self.ssim_weight > 0 else 0.0
         if l1_w == 0.0 and s_w == 0.0 and not self.use_perceptual:
             return 0.0                         # the reference returns the python float 0.0 here
-        return _SSIML1.apply(output, target, l1_w, s_w, self.sigma, self.val_range, 0, self)
+        total = None
+        if l1_w != 0.0 or s_w != 0.0:
+            total = _SSIML1.apply(output, target, l1_w, s_w, self.sigma, self.val_range, 0, self)
+        if self.use_perceptual:                # losses.py:229-236
+            perc = self.perceptual_loss(output, target)
+            self.last_perceptual = perc.detach()
+            total = self.perceptual_weight * perc if total is None else total + self.perceptual_weight * perc
+        return total
 
 
 class SSIM(nn.Module):

@@ -100,9 +100,9 @@ def train(args):
     if args.cpu or not torch.cuda.is_available():
         raise SystemExit("this build runs on MI355X only (hand-written HIP kernels, no CPU fallback): "
                          "--cpu / a machine without a GPU is not supported")
-    if args.perceptual_weight > 0:
-        raise SystemExit("perceptual_weight > 0 needs torchvision's pretrained VGG19, which is not available "
-                         "in this build (see DESIGN.md)")
+    if args.perceptual_weight > 0 and not os.environ.get("MRISR_VGG19_WEIGHTS"):
+        log_message("perceptual_weight > 0 without MRISR_VGG19_WEIGHTS: torchvision's pretrained VGG19 cannot be "
+                    "downloaded here, the feature extractor is RANDOMLY initialised (see DESIGN.md)", "warning")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

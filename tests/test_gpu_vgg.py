@@ -1,0 +1,185 @@
+"""GPU parity of the VGG19 perceptual branch (reference utils/losses.py:83-151) against the oracle's restatement
+(oracle/losses_ref.py) on the SAME random weights.
+
+PARITY UNPINNED: torchvision and its ImageNet weights are absent offline and the reference holds no fixture for this
+branch, so these tests pin the HIP path to the oracle's restatement of the published VGG19-E architecture, not to
+reference outputs.  Tolerances: fp32 path loss <= 2e-5 relative, input gradient <= 2e-4 of its max; bf16 path loss
+<= 3e-2 relative, gradient cosine >= 0.95.
+"""
+import ctypes as C
+import os
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mri_superresolution_amd import _lib as L                                   # noqa: E402
+from mri_superresolution_amd.utils.losses import CombinedLoss, PerceptualLoss, VGGFeatureExtractor  # noqa: E402
+from oracle import losses_ref                                                   # noqa: E402
+from oracle.inputs import make_pair                                             # noqa: E402
+
+from hiputil import DEV, nchw, nhwc, pack, stream                               # noqa: E402
+
+
+def _report(line):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_report.txt"), "a") as fh:
+            fh.write(line + "\n")
+
+
+def _grad_check(got, ref, tol, what):
+    """Gradient parity with the piecewise-linear stack in mind: a ReLU / max-pool input within rounding distance of
+    its kink can be gated differently by two fp32 implementations (the fp32 CPU oracle itself does this against its
+    fp64 run: idx=17, seed 0), which moves the gradient inside one receptive field by O(1 %).  Such a flip is accepted
+    when it is local (<= 5 % of the pixels beyond tolerance, relative L2 <= 1e-2); everything else must meet `tol`."""
+    mx = ref.abs().max().item()
+    err = (got - ref).abs()
+    bad = err > tol * mx
+    frac = bad.float().mean().item()
+    l2 = (got - ref).norm().item() / ref.norm().item()
+    assert frac <= 0.05 and l2 <= 1e-2, f"{what}: {frac:.3f} of the gradient beyond {tol:g}, relative L2 {l2:.2e}"
+    return err.max().item() / mx, frac
+
+
+def _perc(idx, loss_type, dtype, seed=0):
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = PerceptualLoss(feature_layer_idx=idx, loss_type=loss_type, compute_dtype=dtype)
+    # biases away from zero so that the bias path is exercised
+    for mod in m.feature_extractor.features:
+        if isinstance(mod, torch.nn.Conv2d):
+            mod.bias.data.normal_(0, 0.05)
+    weights = [(mod.weight.detach().clone(), mod.bias.detach().clone())
+               for mod in m.feature_extractor.features if isinstance(mod, torch.nn.Conv2d)]
+    return m.cuda(), weights
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 7, 9, 8)])
+def test_maxpool2_forward_backward(dt, shape):
+    n, h, w, c = shape
+    torch.manual_seed(3)
+    x = torch.randn(n, c, h, w).relu()            # ReLU output: exact zeros and ties occur
+    x[0, :, 0:2, 0:2] = 0.5                       # a full tie: the first element must win
+    tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+    xr = x.to(tdt).float().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 2)
+    dy = torch.randn_like(y_ref).to(tdt).float()
+    y_ref.backward(dy)
+    gate_ref = xr.grad * (xr.detach() > 0)
+    xd = nhwc(x, dt)
+    out = torch.empty((n, h // 2, w // 2, c), dtype=tdt, device=DEV)
+    L.call("mrisr_maxpool2_forward", dt, xd.data_ptr(), out.data_ptr(), n, h, w, c, stream())
+    assert torch.equal(nchw(out), y_ref.detach())
+    dyd = nhwc(dy, dt)
+    for gate, ref in ((0, xr.grad), (1, gate_ref)):
+        dx = torch.full((n, h, w, c), 7.0, dtype=tdt, device=DEV)
+        L.call("mrisr_maxpool2_backward", dt, xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, gate, stream())
+        assert torch.equal(nchw(dx), ref)
+
+
+@pytest.mark.parametrize("dt,tol", [(L.F32, 2e-5), (L.BF16, 2e-2)])
+def test_conv_relu_mask_epilogue(dt, tol):
+    """dgrad-style conv whose epilogue applies the ReLU backward: out = conv(x) * [mask > 0]."""
+    torch.manual_seed(5)
+    n, h, w, cin, cout = 2, 20, 37, 32, 64
+    tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+    x = torch.randn(n, cin, h, w).to(tdt).float()
+    wt = (torch.randn(cout, cin, 3, 3) * 0.1)
+    mask = torch.randn(n, cout, h, w).relu().to(tdt).float()
+    ref = F.conv2d(x, wt.to(tdt).float(), padding=1) * (mask > 0)
+    xd, md = nhwc(x, dt), nhwc(mask, dt)
+    wp = pack(wt, dt)
+    out = torch.empty((n, h, w, cout), dtype=tdt, device=DEV)
+    d = L.ConvDesc()
+    d.dtype, d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.nsrc = dt, n, h, w, cin, cout, 3, 1
+    d.combine, d.out_mode = L.COMBINE_CONCAT, L.OUT_PLAIN
+    d.src[0].ptr, d.src[0].C, d.src[0].H, d.src[0].W = xd.data_ptr(), cin, h, w
+    d.src[0].mode, d.src[0].spatial = L.SRC_RAW, L.SP_NONE
+    d.wpacked, d.out, d.relu_mask = wp.data_ptr(), out.data_ptr(), md.data_ptr()
+    L.call("mrisr_conv_forward", C.byref(d), stream())
+    got = nchw(out)
+    assert torch.equal(got == 0, (ref == 0) | (got == 0))
+    assert (got[(mask <= 0)] == 0).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("idx,loss_type", [(35, "l1"), (35, "mse"), (3, "l1"), (7, "l1"), (9, "mse"), (17, "l2")])
+def test_perceptual_fp32_matches_oracle(idx, loss_type):
+    m, weights = _perc(idx, loss_type, torch.float32)
+    low, high = make_pair(2, 16, 16, 7)            # high: (2,1,32,32) smooth image
+    gen = (high + 0.1 * torch.randn_like(high)).clamp(0, 1)
+    # the oracle runs in float64: the arbiter between two fp32 implementations
+    g_ref = gen.double().clone().requires_grad_(True)
+    ref = losses_ref.perceptual_loss([(w.double(), b.double()) for w, b in weights], g_ref, high.double(), idx, loss_type)
+    ref.backward()
+    g = gen.cuda().requires_grad_(True)
+    loss = m(g, high.cuda())
+    (3.0 * loss).backward()                        # non-unit upstream gradient
+    rel = abs(loss.item() - ref.item()) / abs(ref.item())
+    gerr, frac = _grad_check(g.grad.cpu().double() / 3.0, g_ref.grad, 2e-4, f"idx={idx} {loss_type}")
+    _report(f"perceptual fp32 idx={idx} {loss_type}: loss {loss.item():.6f} vs oracle(f64) {ref.item():.6f} "
+            f"(rel {rel:.1e}), input-grad err/max {gerr:.1e}, fraction beyond 2e-4: {frac:.4f}")
+    assert rel <= 2e-5, (loss.item(), ref.item())
+
+
+def test_perceptual_bf16_close_to_oracle():
+    m, weights = _perc(35, "l1", torch.bfloat16)
+    low, high = make_pair(2, 32, 32, 9)            # (2,1,64,64)
+    gen = (high + 0.1 * torch.randn_like(high)).clamp(0, 1)
+    g_ref = gen.clone().requires_grad_(True)
+    ref = losses_ref.perceptual_loss(weights, g_ref, high, 35, "l1")
+    ref.backward()
+    g = gen.cuda().requires_grad_(True)
+    loss = m(g, high.cuda())
+    loss.backward()
+    rel = abs(loss.item() - ref.item()) / abs(ref.item())
+    cos = F.cosine_similarity(g.grad.cpu().flatten(), g_ref.grad.flatten(), dim=0).item()
+    _report(f"perceptual bf16 idx=35 l1: loss {loss.item():.6f} vs oracle {ref.item():.6f} (rel {rel:.1e}), grad cosine {cos:.4f}")
+    assert rel <= 3e-2 and cos >= 0.95, (rel, cos)   # measured 2.8e-3 / 0.9675 (L1: sign() of bf16-rounded feature differences)
+
+
+def test_feature_extractor_forward_and_state_dict_keys():
+    torch.manual_seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fe = VGGFeatureExtractor(feature_layer_idx=8, compute_dtype=torch.float32).cuda()
+    keys = set(fe.state_dict().keys())
+    assert {"features.0.weight", "features.0.bias", "features.7.weight", "mean", "std"} <= keys
+    assert all(not p.requires_grad for p in fe.parameters())
+    x = torch.rand(1, 1, 24, 40)
+    weights = [(mod.weight.detach().cpu(), mod.bias.detach().cpu()) for mod in fe.features if isinstance(mod, torch.nn.Conv2d)]
+    ref = losses_ref.vgg_features(weights, x, 8)
+    got = fe(x.cuda()).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_combined_loss_with_perceptual_term():
+    torch.manual_seed(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        crit = CombinedLoss(ssim_weight=0.4, perceptual_weight=0.1, device=torch.device("cuda"))
+    crit.perceptual_loss.feature_extractor.set_compute_dtype(torch.float32)
+    crit = crit.cuda()
+    fe = crit.perceptual_loss.feature_extractor
+    weights = [(mod.weight.detach().cpu(), mod.bias.detach().cpu()) for mod in fe.features if isinstance(mod, torch.nn.Conv2d)]
+    low, high = make_pair(2, 16, 16, 11)
+    gen = (high + 0.05 * torch.randn_like(high)).clamp(0, 1)
+    g_ref = gen.clone().requires_grad_(True)
+    ref = losses_ref.combined_loss(g_ref, high, 0.4, 0.1,
+                                   perceptual_fn=lambda a, b: losses_ref.perceptual_loss(weights, a, b, 35, "l1"))
+    ref.backward()
+    g = gen.cuda().requires_grad_(True)
+    loss = crit(g, high.cuda())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 2e-6
+    _grad_check(g.grad.cpu(), g_ref.grad, 5e-4, "CombinedLoss(0.4, 0.1)")
+    with pytest.raises(ValueError):
+        CombinedLoss(ssim_weight=0.7, perceptual_weight=0.5)
