@@ -76,6 +76,22 @@ template <typename T> __device__ __forceinline__ void store_vec16(T* p, const Ve
     *reinterpret_cast<decltype(r.v)*>(p) = r.v;
 }
 
+// Explicitly GLOBAL-address-space accesses.  Pointers that went through an opaque inline asm (pin_params) lose
+// their inferred address space and hipcc falls back to FLAT instructions, which count on lgkmcnt as well as
+// vmcnt: every LDS wait then also waits for the outstanding global prefetch loads / epilogue stores.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ Vec16<T> gload_vec16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const GLOBAL_AS decltype(r.v)*>((const GLOBAL_AS char*)p);
+    return r;
+}
+template <typename V> __device__ __forceinline__ V gload(const void* p) {
+    return *reinterpret_cast<const GLOBAL_AS V*>((const GLOBAL_AS char*)p);
+}
+template <typename V> __device__ __forceinline__ void gstore(void* p, const V& v) {
+    *reinterpret_cast<GLOBAL_AS V*>((GLOBAL_AS char*)p) = v;
+}
+
 __device__ __forceinline__ float lrelu(float x) { return fmaxf(x, LRELU_SLOPE * x); }   // slope < 1
 
 // ---------------------------------------------------------------- wave / block reductions
@@ -96,10 +112,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add((GLOBAL_AS double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add((GLOBAL_AS float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // bilinear x2 align_corners=True source coordinate, as aten's area_pixel_compute_source_index:

@@ -21,6 +21,12 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 constexpr int kHaloRowBytes = 80;
 __device__ __forceinline__ int halo_off(int row, int chunk) { return row * kHaloRowBytes + (chunk << 4); }
 
+// forward kernel LDS budget: two halo tiles of kMaxHaloIter*64 rows (every commit slot has a row, so the LDS stores
+// need no bounds predicate) + the weight images + BN floats of bias
+static inline size_t conv_halo_bytes() { return (size_t)kMaxHaloIter * 64 * kHaloRowBytes; }
+static inline bool conv_weights_stationary(int nchunks, size_t wimg) {
+    return nchunks * wimg + 2 * conv_halo_bytes() + 64 * sizeof(float) <= 158 * 1024;
+}
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
 static inline int conv_bk(int dtype) { return dtype == MRISR_BF16 ? 32 : 16; }
 
@@ -122,21 +128,21 @@ __device__ __forceinline__ void halo_geom_yx(HaloGeom<SPATIAL>& g, int i, int hy
                                              int pad, int n, int ty0, int tx0, const ConvParams& p) {
     int o0 = -1;
     const int y = ty0 + hy - pad, x = tx0 + hx - pad;
-    const bool inside = slot_ok && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const bool inside = slot_ok & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
     const SrcDev& s0 = p.src[0];
     if constexpr (SPATIAL == MRISR_SP_NONE) {
-        int o1 = -1;
-        if (inside) {
-            const int ys = y - s0.off_y, xs = x - s0.off_x;
-            if (ys >= 0 && ys < s0.H && xs >= 0 && xs < s0.W) o0 = ((n * s0.H + ys) * s0.W + xs) * s0.C;
-            if (p.nsrc > 1) {
-                const SrcDev& s1 = p.src[1];
-                const int y1 = y - s1.off_y, x1 = x - s1.off_x;
-                if (y1 >= 0 && y1 < s1.H && x1 >= 0 && x1 < s1.W) o1 = ((n * s1.H + y1) * s1.W + x1) * s1.C;
-            }
-        }
+        // branch-free (selects): this runs for 6 slots at every tile change of the persistent forward kernel.
+        // (unsigned)(v) < (unsigned)n  <=>  0 <= v < n
+        const int ys = y - s0.off_y, xs = x - s0.off_x;
+        const bool ok0 = inside & ((unsigned)ys < (unsigned)s0.H) & ((unsigned)xs < (unsigned)s0.W);
+        const int e0 = ((n * s0.H + ys) * s0.W + xs) * s0.C;
+        o0 = ok0 ? e0 : -1;
+        const SrcDev& s1 = p.src[1];
+        const int y1 = y - s1.off_y, x1 = x - s1.off_x;
+        const bool ok1 = inside & (p.nsrc > 1) & ((unsigned)y1 < (unsigned)s1.H) & ((unsigned)x1 < (unsigned)s1.W);
+        const int e1 = ((n * s1.H + y1) * s1.W + x1) * s1.C;
         g.off0[i] = o0;
-        g.off1[i] = o1;
+        g.off1[i] = ok1 ? e1 : -1;
     } else if constexpr (SPATIAL == MRISR_SP_POOL2) {
         if (inside) o0 = ((n * s0.H + 2 * y) * s0.W + 2 * x) * s0.C;
         g.off0[i] = o0;
@@ -230,8 +236,8 @@ __device__ __forceinline__ void load_affine(const SrcDev& s, int n, int c, float
     if (s.mode == MRISR_SRC_NORM && c >= 0) {
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(s.scale + (size_t)n * s.C + c + e);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(s.shift + (size_t)n * s.C + c + e);
+            const f32x4 a = gload<f32x4>(s.scale + (size_t)n * s.C + c + e);
+            const f32x4 b = gload<f32x4>(s.shift + (size_t)n * s.C + c + e);
             sc[e] = a[0]; sc[e + 1] = a[1]; sc[e + 2] = a[2]; sc[e + 3] = a[3];
             sh[e] = b[0]; sh[e + 1] = b[1]; sh[e + 2] = b[2]; sh[e + 3] = b[3];
         }

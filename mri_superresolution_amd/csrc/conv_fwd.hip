@@ -12,6 +12,8 @@
 // channels per register quad, so NHWC stores are 8/16-byte pieces.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 template <typename T> struct Mma;
@@ -43,6 +45,7 @@ struct Prefetch {
     float sc[Vec16<T>::N], sh[Vec16<T>::N];       // GroupNorm affine of the chunk's channels (source 0 / the only one)
     float sc1[NH == 2 ? Vec16<T>::N : 1], sh1[NH == 2 ? Vec16<T>::N : 1];   // blend: source 1
     int mask, mode;
+    float slope;                                  // NH == 1: activation as max(y, slope*y): 0.2 NORM, 1 RAW, 0 RELU
 };
 
 constexpr int kFwdThreads = 512;    // two 4-wave halves working in antiphase
@@ -73,9 +76,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     const int TW = 1 << p.tw_log2, TH = p.th;
     const int hw = TW + 2 * PAD, hh = TH + 2 * PAD;
     const int npix_halo = hw * hh;
-    const int halo_bytes = npix_halo * kHaloRowBytes;
+    constexpr int halo_bytes = kMaxHaloIter * 64 * kHaloRowBytes;   // full slots: commits are unpredicated
     char* lds_halo = smem + half * halo_bytes;
     char* lds_w = smem + 2 * halo_bytes + (WS ? 0 : half * (WIMG_VECS * 16));
+    float* lds_bias = reinterpret_cast<float*>(smem + 2 * halo_bytes + (WS ? p.nchunks : 2) * (WIMG_VECS * 16));   // [BN]
 
     // this workgroup: one cout block, tiles [bt0, bt1); this half: [tile0, tile1)
     const int cb = blockIdx.x % p.ncb;
@@ -98,12 +102,14 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     constexpr bool pf_halo = NH > 0;
 
     float blend_a = 0.f;
-    if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
+    if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-gload<float>(p.blend_alpha)));
 
     if constexpr (WS) {   // weights-stationary: every cin chunk's image is loaded once, by all 512 threads
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase);
-        for (int v = threadIdx.x; v < p.nchunks * WIMG_VECS; v += kFwdThreads) reinterpret_cast<u32x4*>(lds_w)[v] = wsrc[v];
+        for (int v = threadIdx.x; v < p.nchunks * WIMG_VECS; v += kFwdThreads) reinterpret_cast<u32x4*>(lds_w)[v] = gload<u32x4>(wsrc + v);
     }
+    const bool has_br = p.bias != nullptr || p.relu_out != 0;      // block-uniform: epilogue with bias / ReLU
+    if (threadIdx.x < BN) lds_bias[threadIdx.x] = (p.bias && bn0 + (int)threadIdx.x < p.Cout) ? gload<float>(p.bias + bn0 + threadIdx.x) : 0.f;
 
     // per-lane LDS byte offsets of its two pixels' halo rows (tap (0,0), k-step 0) and of its weight row
     int xb[2];
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int v = t + j * kConvThreads;
-                if (v < WIMG_VECS) pf.w[j].v = *reinterpret_cast<const decltype(pf.w[j].v)*>(wsrc + v);
+                if (v < WIMG_VECS) pf.w[j].v = gload<decltype(pf.w[j].v)>(wsrc + v);
             }
         }
         if constexpr (pf_halo) {
@@ -188,17 +194,27 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             pf.mode = p.src[which].mode;
             const T* base = (const T*)p.src[which].ptr;
             int mask = 0;
+            if constexpr (NH == 1) {
+                // branch-free: every slot loads (masked slots from element 0 of the tensor, a valid address) and the
+                // validity goes into a bit mask -> six back-to-back global_load_dwordx4, no exec juggling
+                pf.slope = pf.mode == MRISR_SRC_NORM ? LRELU_SLOPE : (pf.mode == MRISR_SRC_RELU ? 0.f : 1.f);
+                const int csafe = cs >= 0 ? cs : 0;
+#pragma unroll
+                for (int i = 0; i < kMaxHaloIter; ++i) {
+                    const int o = which ? geom.off1[i] : geom.off0[i];
+                    const bool ok = o >= 0 && cs >= 0;
+                    pf.h[i][0] = gload_vec16(base + (ok ? o : 0) + csafe);
+                    mask |= (ok ? 1 : 0) << i;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < kMaxHaloIter; ++i) {
                 if constexpr (NH == 1) {
-                    const int o = which ? geom.off1[i] : geom.off0[i];
-                    if (o >= 0 && cs >= 0) { pf.h[i][0] = load_vec16(base + o + cs); mask |= 1 << i; }
-                    else pf.h[i][0].zero();
                 } else if constexpr (NH == 2) {
                     const int o0 = geom.off0[i], o1 = geom.off1[i];
                     if (o0 >= 0 && o1 >= 0 && cs >= 0) {
-                        pf.h[i][0] = load_vec16(base + o0 + cs);
-                        pf.h[i][1] = load_vec16((const T*)p.src[1].ptr + o1 + cs);
+                        pf.h[i][0] = gload_vec16(base + o0 + cs);
+                        pf.h[i][1] = gload_vec16((const T*)p.src[1].ptr + o1 + cs);
                         mask |= 1 << i;
                     } else { pf.h[i][0].zero(); pf.h[i][1].zero(); }
                 } else {
@@ -211,8 +227,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                             d2 = ((upflags >> (2 * i)) & 1) ? p.src[0].W * p.src[0].C : 0;
                         }
                         const T* b = base + o + cs;
-                        pf.h[i][0] = load_vec16(b); pf.h[i][1] = load_vec16(b + d1);
-                        pf.h[i][2] = load_vec16(b + d2); pf.h[i][3] = load_vec16(b + d2 + d1);
+                        pf.h[i][0] = gload_vec16(b); pf.h[i][1] = gload_vec16(b + d1);
+                        pf.h[i][2] = gload_vec16(b + d2); pf.h[i][3] = gload_vec16(b + d2 + d1);
                         mask |= 1 << i;
                     } else {
 #pragma unroll
@@ -233,14 +249,26 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 if (v < WIMG_VECS) *reinterpret_cast<decltype(pf.w[j].v)*>(lds_w + (size_t)v * 16) = pf.w[j].v;
             }
         }
-        if constexpr (pf_halo) {
+        if constexpr (NH == 1) {
+            // straight-line: y = x*sc+sh, act = max(y, slope*y), masked slots -> 0, unpredicated 16-B LDS store
+#pragma unroll
+            for (int i = 0; i < kMaxHaloIter; ++i) {
+                Vec16<T> v = pf.h[i][0];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float y = fmaf(v.get(e), pf.sc[e], pf.sh[e]);
+                    v.set(e, fmaxf(y, pf.slope * y));
+                }
+                if (!((pf.mask >> i) & 1)) v.zero();
+                *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots' temporaries live at a time
+            }
+        } else if constexpr (pf_halo) {
 #pragma unroll
             for (int i = 0; i < kMaxHaloIter; ++i) {
                 Vec16<T> v = pf.h[i][0];
                 if ((pf.mask >> i) & 1) {
-                    if constexpr (NH == 1) {
-                        transform_vec(v, pf.mode, pf.sc, pf.sh);
-                    } else if constexpr (NH == 2) {
+                    if constexpr (NH == 2) {
                         float fa[VEC], fb[VEC];
                         transform_f(pf.h[i][0], fa, p.src[0].mode, pf.sc, pf.sh);
                         transform_f(pf.h[i][1], fb, p.src[1].mode, pf.sc1, pf.sh1);
@@ -279,7 +307,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int co = bn0 + ni * 32 + 8 * q + 4 * lh;
+                int co = bn0 + ni * 32 + 8 * q + 4 * lh;
+                // opaque: otherwise the 8 group offsets (co / gs, 64-bit) are hoisted out of the persistent loop
+                // and sit in 16 VGPRs for a value needed once per image
+                asm volatile("" : "+v"(co));
                 const float s = half_wave_sum(st_s[ni][q]), ss = half_wave_sum(st_ss[ni][q]);
                 if (lr == 0 && co < p.Cout) {
                     const int g = co / gs;
@@ -291,7 +322,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 st_ss[ni][q] = 0.f;
             }
     };
-    // epilogue of a finished tile: bias, (relu), NHWC / pixel-shuffled store, per-lane GroupNorm partial sums
+    // epilogue of a finished tile: bias, (relu), NHWC / pixel-shuffled store, per-lane GroupNorm partial sums.
+    // Straight-line per (pixel row mi, cout fragment ni): no per-quad branches (the bias comes from LDS, pixels
+    // outside the image and channels >= Cout are handled by multiplying the statistics with 0/1 and by predicating
+    // only the stores); bias / ReLU sit behind one block-uniform branch per fragment.
     auto epilogue = [&](int n, int ty0, int tx0) {
         if (p.dbg & 16) return;
         T* outp = (T*)p.out;
@@ -300,9 +334,20 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             const int pl = wave * 64 + mi * 32 + lr;
             const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
             const bool pv = oy < p.H && ox < p.W;
+            const float pvf = pv ? 1.f : 0.f;
             const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
+                if (has_br) {   // block-uniform: bias (from LDS) and ReLU applied in place on the accumulators
+                    const float floor_v = p.relu_out ? 0.f : -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // (channels >= Cout: zero weights and a zero LDS bias keep them at exactly 0)
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds_bias + ni * 32 + 8 * q + 4 * lh);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ni][mi][4 * q + j] = fmaxf(acc[ni][mi][4 * q + j] + b[j], floor_v);
+                    }
+                }
                 u32x2 packed[4];          // bf16 plain epilogue: the 4 quads of this fragment, packed
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -313,37 +358,28 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         v[j] = acc[ni][mi][4 * q + j];
                         acc[ni][mi][4 * q + j] = 0.f;
                     }
-                    const bool ok = pv && co < p.Cout;
-                    if (ok) {
-                        if (p.bias) {
-                            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + co);
-                            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-                        }
-                        if (p.relu_out) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                        }
-                        st_s[ni][q] += (v[0] + v[1]) + (v[2] + v[3]);
-                        st_ss[ni][q] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    }
+                    const float qs = (v[0] + v[1]) + (v[2] + v[3]);
+                    const float qq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                    st_s[ni][q] = fmaf(pvf, qs, st_s[ni][q]);
+                    st_ss[ni][q] = fmaf(pvf, qq, st_ss[ni][q]);
                     if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
                         union { bf16x4 b; u32x2 u; } cv;
                         cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         packed[q] = cv.u;
-                    } else if (ok && !(p.dbg & 1)) {
+                    } else if (pv && co < p.Cout && !(p.dbg & 1)) {
                         if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2) {
                             if constexpr (EPI == kEpiMask) {   // ReLU backward: keep the gradient where the activation is > 0
-                                const f32x4 m = *reinterpret_cast<const f32x4*>((const float*)p.mask + pix * p.Cout + co);
+                                const f32x4 m = gload<f32x4>((const float*)p.mask + pix * p.Cout + co);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
                             }
-                            *reinterpret_cast<f32x4*>(outp + pix * p.Cout + co) = f32x4{v[0], v[1], v[2], v[3]};
+                            gstore(outp + pix * p.Cout + co, f32x4{v[0], v[1], v[2], v[3]});
                         } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
                             const int C4 = p.Cout >> 2, c4 = co >> 2;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                outp[((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4] =
-                                    from_f32<T>(v[j]);
+                                gstore(outp + ((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4,
+                                       from_f32<T>(v[j]));
                         }
                     }
                 }
@@ -360,7 +396,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         const int co8 = bn0 + ni * 32 + 8 * (q + lh);      // first of the 8 channels this lane now owns
                         if (pv && co8 < p.Cout && !(p.dbg & 1)) {
                             if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
-                                const u32x4 m = *reinterpret_cast<const u32x4*>((const T*)p.mask + pix * p.Cout + co8);
+                                const u32x4 m = gload<u32x4>((const T*)p.mask + pix * p.Cout + co8);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const unsigned lo = __uint_as_float(m[k] << 16) > 0.f ? 0x0000ffffu : 0u;
@@ -368,14 +404,14 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                                     o[k] &= (lo | hi);
                                 }
                             }
-                            *reinterpret_cast<u32x4*>(outp + pix * p.Cout + co8) = o;
+                            gstore(outp + pix * p.Cout + co8, o);
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // bound the scheduling window: one (mi, ni) group's temporaries live at a time
             }
         }
     };
-
     // ---- schedule: commit phase c at tick 2c + half, MFMA phase c at tick 2c + 1 + half
     int cur_tile = tile0, cur_kc = 0, cur_n = 0, cur_ty0 = 0, cur_tx0 = 0;       // item c
     int nxt_tile = tile0, nxt_kc = 0, nxt_n = 0, nxt_ty0 = 0, nxt_tx0 = 0;       // item c + 1
@@ -445,6 +481,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     }
 }
 
+#ifndef MRISR_KERNEL_ONLY   // (tuning: a translation unit that instantiates single kernels includes this file with it set)
 // ------------------------------------------------------------------------------------------------
 // Weight packer: fp32 [Cout][k][k][Cin] -> sequence of LDS images [cout block][cin chunk][tap][BN][64 B]
 // (swizzled exactly as the kernel reads them).  transpose_flip: the dgrad operand, i.e. the image of
@@ -569,11 +606,12 @@ int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int 
 template <typename T, int BN, int SPATIAL, int KS>
 static int launch_conv(ConvParams& p, hipStream_t s) {
     const int TW = 1 << p.tw_log2, pad = KS / 2;
-    const size_t halo_bytes = (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * kHaloRowBytes;
+    (void)TW; (void)pad;
+    const size_t halo_bytes = conv_halo_bytes();
     const size_t wimg = (size_t)KS * KS * BN * kRowBytes;
     // weights-stationary when every cin chunk fits next to the two halo tiles
-    p.ws = (p.nchunks * wimg + 2 * halo_bytes <= 150 * 1024) ? 1 : 0;
-    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg;
+    p.ws = conv_weights_stationary(p.nchunks, wimg) ? 1 : 0;
+    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg + BN * sizeof(float);
     p.ntiles = p.N * p.tiles_y * p.tiles_x;
     int per_cb = num_cus() / p.ncb;                     // persistent workgroups per cout block, one per CU
     if (per_cb < 1) per_cb = 1;
@@ -653,10 +691,9 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     if (wgrad) {
         snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d>", t, loader, d->ksize);
     } else {
-        const int BN = conv_choose_bn(d->Cout), pad = d->ksize / 2, TW = 1 << p.tw_log2;
-        const size_t halo = (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * kHaloRowBytes;
+        const int BN = conv_choose_bn(d->Cout);
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
-        const int ws = (p.nchunks * wimg + 2 * halo <= 150 * 1024) ? 1 : 0;
+        const int ws = conv_weights_stationary(p.nchunks, wimg) ? 1 : 0;
         snprintf(out, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", t, BN, loader, d->ksize, ws,
                  d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 ? 1 : (d->relu_mask ? kEpiMask : 0));
     }
@@ -678,3 +715,4 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     if (d->dtype == MRISR_BF16) return BN == 64 ? dispatch_conv_sp<bf16_t, 64>(p, sp, d->ksize, s) : dispatch_conv_sp<bf16_t, 32>(p, sp, d->ksize, s);
     return BN == 64 ? dispatch_conv_sp<float, 64>(p, sp, d->ksize, s) : dispatch_conv_sp<float, 32>(p, sp, d->ksize, s);
 }
+#endif  // MRISR_KERNEL_ONLY
