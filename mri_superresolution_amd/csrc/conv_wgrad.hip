@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     const int total_tiles = p.N * p.tiles_y * p.tiles_x;
 
     float blend_a = 0.f;
-    if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
+    if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-gload<float>(p.blend_alpha)));
 
     // wave roles: tap group, 32x32 fragment pair, and - when the channel block holds fewer than 4 pairs
     // (Cout or Cin <= 32) - a share of the k-steps, so no wave multiplies padding
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     Vec16<T> pdy[4];
     Vec16<T> ph[kWgSlots][NH > 0 ? NH : 1];
     float sc[VEC], sh[VEC], sc1[NH == 2 ? VEC : 1], sh1[NH == 2 ? VEC : 1];
-    int pmask = 0, pmode = 0;
+    int pmask = 0, pmode = 0, dymask = 0;
+    float pslope = 1.f;                 // NH == 1: activation as max(y, slope*y): 0.2 NORM, 1 RAW, 0 RELU
 
     auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
         const int tx = tile % p.tiles_x;
@@ -112,15 +113,17 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     auto issue = [&](int n, int ty0, int tx0) {
         if (p.dbg & 4) return;
         const int c = co0 + ch8 * VEC;
+        int dm = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pl = (t >> 3) + 64 * i;
             const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
-            if (oy < p.H && ox < p.W && c < p.Cout)
-                pdy[i] = load_vec16((const T*)p.dy + ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + c);
-            else
-                pdy[i].zero();
+            // unconditional load from a clamped address + validity bit: four back-to-back loads, no exec juggling
+            const bool ok = oy < p.H && ox < p.W && c < p.Cout;
+            pdy[i] = gload_vec16((const T*)p.dy + (ok ? ((size_t)(n * p.H + oy) * p.W + ox) * p.Cout + c : 0));
+            dm |= (ok ? 1 : 0) << i;
         }
+        dymask = dm;
         if constexpr (NH > 0) {
             int which = 0, cs = c_in;
             if constexpr (NH == 1) {
@@ -132,19 +135,21 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             pmode = p.src[which].mode;
             const T* base = (const T*)p.src[which].ptr;
             int mask = 0;
+            const int csafe = cs >= 0 ? cs : 0;
+            if constexpr (NH == 1) pslope = pmode == MRISR_SRC_NORM ? LRELU_SLOPE : (pmode == MRISR_SRC_RELU ? 0.f : 1.f);
 #pragma unroll
             for (int i = 0; i < kWgSlots; ++i) {
                 if constexpr (NH == 1) {
                     const int o = which ? geom.off1[i] : geom.off0[i];
-                    if (o >= 0 && cs >= 0) { ph[i][0] = load_vec16(base + o + cs); mask |= 1 << i; }
-                    else ph[i][0].zero();
+                    const bool ok = o >= 0 && cs >= 0;
+                    ph[i][0] = gload_vec16(base + (ok ? o : 0) + csafe);
+                    mask |= (ok ? 1 : 0) << i;
                 } else {
                     const int o0 = geom.off0[i], o1 = geom.off1[i];
-                    if (o0 >= 0 && o1 >= 0 && cs >= 0) {
-                        ph[i][0] = load_vec16(base + o0 + cs);
-                        ph[i][1] = load_vec16((const T*)p.src[1].ptr + o1 + cs);
-                        mask |= 1 << i;
-                    } else { ph[i][0].zero(); ph[i][1].zero(); }
+                    const bool ok = o0 >= 0 && o1 >= 0 && cs >= 0;
+                    ph[i][0] = gload_vec16(base + (ok ? o0 : 0) + csafe);
+                    ph[i][1] = gload_vec16((const T*)p.src[1].ptr + (ok ? o1 : 0) + csafe);
+                    mask |= (ok ? 1 : 0) << i;
                 }
             }
             pmask = mask;
@@ -157,25 +162,32 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pl = (t >> 3) + 64 * i;
-            *reinterpret_cast<decltype(pdy[i].v)*>(lds_dy + lds_off128(pl, ch8 >> 2, ch8 & 3)) = pdy[i].v;
+            Vec16<T> v = pdy[i];
+            if (!((dymask >> i) & 1)) v.zero();
+            *reinterpret_cast<decltype(v.v)*>(lds_dy + lds_off128(pl, ch8 >> 2, ch8 & 3)) = v.v;
         }
         if constexpr (NH > 0) {
 #pragma unroll
             for (int i = 0; i < kWgSlots; ++i) {
                 Vec16<T> v = ph[i][0];
-                if ((pmask >> i) & 1) {
-                    if constexpr (NH == 1) {
-                        transform_vec(v, pmode, sc, sh);
-                    } else {
-                        float fa[VEC], fb[VEC];
-                        transform_f(ph[i][0], fa, p.src[0].mode, sc, sh);
-                        transform_f(ph[i][1], fb, p.src[1].mode, sc1, sh1);
+                if constexpr (NH == 1) {     // straight-line: y = x*sc+sh, act = max(y, slope*y)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) v.set(e, blend_a * fa[e] + (1.f - blend_a) * fb[e]);
+                    for (int e = 0; e < VEC; ++e) {
+                        const float y = fmaf(v.get(e), sc[e], sh[e]);
+                        v.set(e, fmaxf(y, pslope * y));
                     }
+                } else {
+                    float fa[VEC], fb[VEC];
+                    transform_f(ph[i][0], fa, p.src[0].mode, sc, sh);
+                    transform_f(ph[i][1], fb, p.src[1].mode, sc1, sh1);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.set(e, blend_a * fa[e] + (1.f - blend_a) * fb[e]);
                 }
-                if (hyx[i] >= 0)
+                if (!((pmask >> i) & 1)) v.zero();
+                // 3x3: slots 0..4 exist for every tile shape (halo >= 320 pixels), 1x1: slots 0..3 (256 pixels)
+                if (i < (KS == 3 ? kWgSlots - 1 : 4) || hyx[i] >= 0)
                     *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128((t >> 3) + 64 * i, ch8 >> 2, ch8 & 3)) = v.v;
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // gathers (pool / bilinear): load + transform + store here, one slot at a time
@@ -192,23 +204,28 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         }
     };
 
+    // Schedule.  The two waves that share a SIMD (tap groups 0 and 1) run the iteration in opposite orders, so that
+    // one is in its MFMA block while the other does the VALU/LDS-store work of staging the next tile:
+    //   tap group 0:  issue loads(tile k+1) -> MFMA(tile k) -> commit(tile k+1)
+    //   tap group 1:  commit(tile k+1, loads issued one iteration earlier) -> issue loads(tile k+2) -> MFMA(tile k)
+    // Each thread stages its own slots of the double-buffered LDS image; the barrier at the end of iteration k
+    // separates the writes of buffer (k+1)&1 from its reads in iteration k+1 and from its last reads in k-1.
+    const int tgu = __builtin_amdgcn_readfirstlane(tg);      // wave-uniform -> scalar branch
     int tile = blockIdx.y, n = 0, ty0 = 0, tx0 = 0, cur = 0;
+    int pn = 0, pty0 = 0, ptx0 = 0;                           // group 1: tile whose operands are in registers
     if (tile < total_tiles) {
         decode(tile, n, ty0, tx0);
         set_geom(n, ty0, tx0);
         issue(n, ty0, tx0);
         commit(smem, n);
+        if (tgu == 1 && tile + (int)gridDim.y < total_tiles) {
+            decode(tile + gridDim.y, pn, pty0, ptx0);
+            set_geom(pn, pty0, ptx0);
+            issue(pn, pty0, ptx0);
+        }
     }
     __syncthreads();
-    while (tile < total_tiles) {
-        const int nxt = tile + gridDim.y;
-        const bool has_next = nxt < total_tiles;
-        int nn = n, nty0 = ty0, ntx0 = tx0;
-        if (has_next) {
-            decode(nxt, nn, nty0, ntx0);
-            set_geom(nn, nty0, ntx0);
-            issue(nn, nty0, ntx0);              // global loads fly while the MFMAs below run
-        }
+    auto mfma_block = [&]() {
         const char* lds_dy = smem + cur * buf_bytes;
         const char* lds_in = lds_dy + 256 * 128;
         if (p.dbg & 8) {
@@ -256,10 +273,22 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
                 }
             }
         }
-        if (has_next) commit(smem + (cur ^ 1) * buf_bytes, nn);
+    };
+    while (tile < total_tiles) {
+        const int nxt = tile + gridDim.y;
+        const bool has_next = nxt < total_tiles;
+        if (tgu == 1 && has_next) commit(smem + (cur ^ 1) * buf_bytes, pn);       // loads issued one iteration ago
+        const int it = tgu ? nxt + (int)gridDim.y : nxt;                            // tile to start loading now
+        if (it < total_tiles) {
+            decode(it, pn, pty0, ptx0);
+            set_geom(pn, pty0, ptx0);
+            issue(pn, pty0, ptx0);                  // global loads fly while the MFMAs below run
+        }
+        mfma_block();
+        if (tgu == 0 && has_next) commit(smem + (cur ^ 1) * buf_bytes, pn);
         __syncthreads();
         cur ^= 1;
-        tile = nxt; n = nn; ty0 = nty0; tx0 = ntx0;
+        tile = nxt;
     }
 
     // ---- accumulate into dW[co][tap][ci]: lane = ci (128-B contiguous per half wave), regs = co
@@ -279,6 +308,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     }
 }
 
+#ifndef MRISR_KERNEL_ONLY
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who);
 int num_cus();
 
@@ -333,3 +363,4 @@ extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float*
     if (d->dtype == MRISR_BF16) return dispatch_wgrad<bf16_t>(p, d->src[0].spatial, d->ksize, s);
     return dispatch_wgrad<float>(p, d->src[0].spatial, d->ksize, s);
 }
+#endif  // MRISR_KERNEL_ONLY
