@@ -16,6 +16,8 @@
 // Partial sums are added to the fp32 master gradient with 128-byte-segment float atomics.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 template <typename T> struct WgTraits;
@@ -38,7 +40,10 @@ __device__ __forceinline__ bf16x8 tr_read_frag(const char* base0, const char* ba
 
 constexpr int kLoaderBlendW = 3;     // template-only loader kind: sigmoid(alpha)-blend of two sources
 
-template <typename T, int SPATIAL, int KS>
+// FAST: bf16 3x3, 8x32 tiles, Cout and Cin multiples of 64 (every wave owns a full 32x32 fragment pair): only the
+// fully unrolled immediate-offset MFMA block is compiled in (the generic block's hoisted address pieces would
+// otherwise push this variant over the register budget).
+template <typename T, int SPATIAL, int KS, bool FAST = false>
 __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams p = pin_params(p_in);
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     // wave roles: tap group, 32x32 fragment pair, and - when the channel block holds fewer than 4 pairs
     // (Cout or Cin <= 32) - a share of the k-steps, so no wave multiplies padding
     const int tg = wave >> 2;                                 // tap group (1x1: K half)
+    const int tgu = __builtin_amdgcn_readfirstlane(tg);       // the same, as a scalar (uniform branches)
     const int nfo = kBf16 ? (min(p.Cout - co0, BC) > 32 ? 2 : 1) : 1;
     const int nfi = kBf16 ? (min(p.Cin - ci0, BC) > 32 ? 2 : 1) : 1;
     const int npairs = nfo * nfi, kparts = 4 / npairs;        // 1, 2 or 4 pairs
@@ -104,9 +110,19 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         tx0 = tx * TW;
     };
     auto set_geom = [&](int n, int ty0, int tx0) {
+        if constexpr (FAST) {      // halo 10 x 34 known at compile time: slot coordinates recomputed (3 VALU), not kept live
+            int tq = t >> 3;
+            asm volatile("" : "+v"(tq));
 #pragma unroll
-        for (int i = 0; i < kWgSlots; ++i)
-            halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
+            for (int i = 0; i < kWgSlots; ++i) {
+                const int hp = tq + 64 * i, hy = hp / 34;
+                halo_geom_yx<GSP>(geom, i, hy, hp - hy * 34, hp < 340, PAD, n, ty0, tx0, p);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kWgSlots; ++i)
+                halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
+        }
     };
     // channel vector of this thread inside the conv input for the halo: sub-chunk (ch8>>2), chunk (ch8&3)
     const int c_in = ci0 + ch8 * VEC;
@@ -114,9 +130,13 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         if (p.dbg & 4) return;
         const int c = co0 + ch8 * VEC;
         int dm = 0;
+        // opaque copy of the thread index: the per-slot pixel coordinates are 2 VALU ops each to recompute, hoisted
+        // out of the persistent loop they are 8 long-lived VGPRs (and spill)
+        int tq = t >> 3;
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int pl = (t >> 3) + 64 * i;
+            const int pl = tq + 64 * i;
             const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
             // unconditional load from a clamped address + validity bit: four back-to-back loads, no exec juggling
             const bool ok = oy < p.H && ox < p.W && c < p.Cout;
@@ -159,9 +179,11 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         if (p.dbg & 2) return;
         char* lds_dy = buf;
         char* lds_in = buf + 256 * 128;
+        int tq = t >> 3;                       // opaque: the 10 LDS store addresses are recomputed, not kept live
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int pl = (t >> 3) + 64 * i;
+            const int pl = tq + 64 * i;
             Vec16<T> v = pdy[i];
             if (!((dymask >> i) & 1)) v.zero();
             *reinterpret_cast<decltype(v.v)*>(lds_dy + lds_off128(pl, ch8 >> 2, ch8 & 3)) = v.v;
@@ -185,8 +207,8 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
                 }
                 if (!((pmask >> i) & 1)) v.zero();
                 // 3x3: slots 0..4 exist for every tile shape (halo >= 320 pixels), 1x1: slots 0..3 (256 pixels)
-                if (i < (KS == 3 ? kWgSlots - 1 : 4) || hyx[i] >= 0)
-                    *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128((t >> 3) + 64 * i, ch8 >> 2, ch8 & 3)) = v.v;
+                if (i < (KS == 3 ? kWgSlots - 1 : 4) || (FAST ? tq + 64 * i < 340 : hyx[i] >= 0))
+                    *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128(tq + 64 * i, ch8 >> 2, ch8 & 3)) = v.v;
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -210,7 +232,6 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     //   tap group 1:  commit(tile k+1, loads issued one iteration earlier) -> issue loads(tile k+2) -> MFMA(tile k)
     // Each thread stages its own slots of the double-buffered LDS image; the barrier at the end of iteration k
     // separates the writes of buffer (k+1)&1 from its reads in iteration k+1 and from its last reads in k-1.
-    const int tgu = __builtin_amdgcn_readfirstlane(tg);      // wave-uniform -> scalar branch
     int tile = blockIdx.y, n = 0, ty0 = 0, tx0 = 0, cur = 0;
     int pn = 0, pty0 = 0, ptx0 = 0;                           // group 1: tile whose operands are in registers
     if (tile < total_tiles) {
@@ -225,19 +246,74 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         }
     }
     __syncthreads();
+    // Fast path of the MFMA block (bf16, 3x3, 8x32 tiles, every wave owns a full fragment pair): fully unrolled over
+    // the 16 k-steps with the halo width known at compile time, so that every fragment address is one of a few
+    // per-lane base registers plus an immediate - the generic loop below spends ~45 VALU instructions of address
+    // arithmetic per k-step (5 MFMAs) and is VALU-bound.
+    //   B row of (k-step ks, tap): h0 = K + lp, K = (ks>>1)*34 + (ks&1)*16 + tapoff (compile time), lp = 8*lh + gq;
+    //   lds_off128's row swizzle ((h0>>1)&1) depends on K only through K mod 4 -> four per-lane bases.
+    static_assert(!FAST || (kBf16 && KS == 3), "FAST wgrad variant: bf16 3x3 only");
+    int a_lane = 0, b_lane[4] = {0, 0, 0, 0};
+    if constexpr (kBf16) {
+        const int li = lane & 15, gq = li >> 2, gp = li & 3, gr = (lane >> 4) & 1;
+        const int chb = 16 * gr + 4 * gp;
+        const int lp = 8 * lh + gq;
+        const int cbits = (((chb >> 3) & 3) << 4) + ((chb & 4) << 1);
+        a_lane = lp * 128 + ((fo ^ ((gq >> 1) & 1)) << 6) + cbits;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_lane[kk] = 256 * 128 + lp * 128 + ((fi ^ (((kk + gq) >> 1) & 1)) << 6) + cbits;
+    }
+    auto mfma_fast = [&](auto tg_tag) {
+        constexpr int TG = decltype(tg_tag)::value;
+        constexpr int HWC = 32 + 2 * PAD;
+        constexpr int NTG = TG ? NTAPS - NT0 : NT0;       // taps of this group
+        constexpr int NS = 16 * NTG;                      // (k-step, tap) steps, one MFMA each
+        const char* bufp = smem + cur * buf_bytes;
+        const char* ab = bufp + a_lane;
+        const char* bb[4] = {bufp + b_lane[0], bufp + b_lane[1], bufp + b_lane[2], bufp + b_lane[3]};
+        auto load_a = [&](int ks) { return tr_read_frag(ab + ks * 2048, ab + ks * 2048 + 512); };
+        auto load_b = [&](int st) {
+            const int ks = st / NTG, tap = (TG ? NT0 : 0) + st % NTG;
+            const int K = (ks >> 1) * HWC + (ks & 1) * 16 + (tap / KS) * HWC + (tap % KS);
+            const char* b = bb[K & 3] + K * 128;
+            return tr_read_frag(b, b + 512);
+        };
+        // software pipeline: the B fragment of step s+2 and the A fragment of the next k-step are requested before
+        // the MFMA of step s is issued, so two LDS reads are always in flight behind the matrix pipe
+        bf16x8 aq[2], bq[3];
+        aq[0] = load_a(0);
+        bq[0] = load_b(0);
+        bq[1] = load_b(1);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int ks = st / NTG, j = st % NTG;
+            if (st + 2 < NS) bq[(st + 2) % 3] = load_b(st + 2);
+            if (j == 0 && ks + 1 < 16) aq[(ks + 1) & 1] = load_a(ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1], bq[st % 3], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto mfma_block = [&]() {
         const char* lds_dy = smem + cur * buf_bytes;
         const char* lds_in = lds_dy + 256 * 128;
         if (p.dbg & 8) {
+        } else if constexpr (FAST) {
+            if (tgu == 0) mfma_fast(std::integral_constant<int, 0>{});
+            else mfma_fast(std::integral_constant<int, 1>{});
         } else if constexpr (kBf16) {
-            const int li = lane & 15, gq = li >> 2, gp = li & 3, gr = (lane >> 4) & 1;
+            // generic path (small images / channel blocks narrower than 64): keep its per-lane address pieces from
+            // being hoisted out of the persistent loop, where they would cost the fast path ~25 live VGPRs
+            int lane_o = lane, lh_o = lh;
+            asm volatile("" : "+v"(lane_o), "+v"(lh_o));
+            const int li = lane_o & 15, gq = li >> 2, gp = li & 3, gr = (lane_o >> 4) & 1;
             const int chb = 16 * gr + 4 * gp;            // channel inside the 32-wide fragment
             const int c_dy = fo * 32 + chb, c_b = fi * 32 + chb;
             // 1x1: both groups take the single tap and split the k-steps
             const int ks_lo = (NTAPS == 1 ? 8 * tg : 0) + kpart, ks_hi = NTAPS == 1 ? 8 * tg + 8 : 16;
 #pragma unroll 2
             for (int ks = ks_lo; ks < ks_hi; ks += kparts) {
-                const int pk = ks * 16 + 8 * lh + gq;    // pixel (second read: +4)
+                const int pk = ks * 16 + 8 * lh_o + gq;  // pixel (second read: +4)
                 const bf16x8 af = tr_read_frag(
                     lds_dy + lds_off128(pk, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1),
                     lds_dy + lds_off128(pk + 4, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1));
@@ -312,7 +388,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who);
 int num_cus();
 
-template <typename T, int SPATIAL, int KS>
+template <typename T, int SPATIAL, int KS, bool FAST = false>
 static int launch_wgrad(ConvParams& p, hipStream_t s) {
     constexpr int BC = WgTraits<T>::BC;
     const int TW = 1 << p.tw_log2, pad = KS / 2;
@@ -323,7 +399,7 @@ static int launch_wgrad(ConvParams& p, hipStream_t s) {
     if (ksplit > total_tiles) ksplit = total_tiles;
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 65535) ksplit = 65535;
-    auto kern = conv_wgrad_kernel<T, SPATIAL, KS>;
+    auto kern = conv_wgrad_kernel<T, SPATIAL, KS, FAST>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -341,6 +417,10 @@ static int dispatch_wgrad(ConvParams& p, int spatial, int ks, hipStream_t s) {
         return launch_wgrad<T, kLoaderBlendW, 3>(p, s);
     }
     if (ks == 3) {
+        if constexpr (sizeof(T) == 2) {
+            if (spatial == MRISR_SP_NONE && p.tw_log2 == 5 && p.Cout % 64 == 0 && p.Cin % 64 == 0)
+                return launch_wgrad<T, MRISR_SP_NONE, 3, true>(p, s);
+        }
         if (spatial == MRISR_SP_NONE) return launch_wgrad<T, MRISR_SP_NONE, 3>(p, s);
         if (spatial == MRISR_SP_POOL2) return launch_wgrad<T, MRISR_SP_POOL2, 3>(p, s);
         return launch_wgrad<T, MRISR_SP_UP2, 3>(p, s);
