@@ -185,6 +185,9 @@ extern "C" int mrisr_head_forward(int dtype, const void* x, const float* scale, 
 }
 
 // dz = dout * out * (1-out);  da[c] = dz * w[c];  dw[c] += sum dz * act[c];  db += sum dz
+// Thread = (pixel lane, 16-byte channel vector): a wave reads / writes whole pixel rows (C*sizeof(T) contiguous
+// bytes per pixel), so x is fetched once and da is written in full lines (a thread-per-pixel loop over channel
+// vectors re-fetched every line C/VEC times: 1.2 GB read for a 268 MB tensor).
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
@@ -192,47 +195,45 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                                                        T* __restrict__ da, float* __restrict__ dw, float* __restrict__ db,
                                                        int HW, int C, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    extern __shared__ float sm[];   // scale[C], shift[C], w[C], dwacc[C], dbacc
+    extern __shared__ float sm[];   // dwacc[C], dbacc
     const int n = blockIdx.y, t = threadIdx.x;
-    for (int i = t; i < C; i += 256) {
-        sm[i] = scale[(size_t)n * C + i];
-        sm[C + i] = shift[(size_t)n * C + i];
-        sm[2 * C + i] = w[i];
-        sm[3 * C + i] = 0.f;
-    }
-    if (t == 0) sm[4 * C] = 0.f;
+    const int nvec = C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    for (int i = t; i <= C; i += 256) sm[i] = 0.f;
     __syncthreads();
-    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
-    float dbs = 0.f;
-    for (int c = 0; c < C; c += VEC) {           // channel-vector outer loop keeps dw partials in VEC registers
-        float dws[VEC];
+    float sc[VEC], sh[VEC], wv[VEC], dws[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) dws[e] = 0.f;
-        for (int pix = blockIdx.x * pix_per_block + t; pix < pend; pix += 256) {
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = scale[(size_t)n * C + c + e];
+        sh[e] = shift[(size_t)n * C + c + e];
+        wv[e] = w[c + e];
+        dws[e] = 0.f;
+    }
+    float dbs = 0.f;
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    if (pl < ppb) {
+        for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
             const size_t gp = (size_t)n * HW + pix;
             const float o = out[gp];
             const float dz = dout[gp] * o * (1.f - o);
-            if (c == 0) dbs += dz;
+            if (cv == 0) dbs += dz;
             const Vec16<T> v = load_vec16(x + gp * C + c);
             Vec16<T> g;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                dws[e] += dz * lrelu(v.get(e) * sm[c + e] + sm[C + c + e]);
-                g.set(e, dz * sm[2 * C + c + e]);
+                dws[e] += dz * lrelu(v.get(e) * sc[e] + sh[e]);
+                g.set(e, dz * wv[e]);
             }
             store_vec16(da + gp * C + c, g);
         }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float r = wave_sum(dws[e]);
-            if ((t & 63) == 0) atomicAdd(&sm[3 * C + c + e], r);
-        }
+        for (int e = 0; e < VEC; ++e) atomicAdd(&sm[c + e], dws[e]);     // LDS: ppb adders per address, once per block
     }
     dbs = wave_sum(dbs);
-    if ((t & 63) == 0) atomicAdd(&sm[4 * C], dbs);
+    if ((t & 63) == 0) atomicAdd(&sm[C], dbs);
     __syncthreads();
-    for (int i = t; i < C; i += 256) atomic_add_f32(&dw[i], sm[3 * C + i]);
-    if (t == 0) atomic_add_f32(db, sm[4 * C]);
+    for (int i = t; i < C; i += 256) atomic_add_f32(&dw[i], sm[i]);
+    if (t == 0) atomic_add_f32(db, sm[C]);
 }
 
 extern "C" int mrisr_head_backward(int dtype, const void* x, const float* scale, const float* shift, const float* w,
@@ -240,10 +241,10 @@ extern "C" int mrisr_head_backward(int dtype, const void* x, const float* scale,
                                    int W, int C, void* stream) {
     if (!x || !scale || !shift || !w || !out || !dout || !da || !dw || !db) MRISR_FAIL(MRISR_E_ARG, "head_backward: null pointer");
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
-    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "head_backward: C %d", C);
+    if (C % vec || C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "head_backward: C %d", C);
     const int ppblk = 256 * 8;
     dim3 grid(ceil_div(H * W, ppblk), N);
-    const size_t lds = (4 * C + 1) * sizeof(float);
+    const size_t lds = (C + 1) * sizeof(float);
     if (dtype == MRISR_BF16) head_bwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, w, out, dout, (bf16_t*)da, dw, db, H * W, C, ppblk);
     else if (dtype == MRISR_F32) head_bwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)x, scale, shift, w, out, dout, (float*)da, dw, db, H * W, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "head_backward: dtype %d", dtype);

@@ -93,7 +93,10 @@ __device__ __forceinline__ void up2_adjoint_weights(int y, int in_size, int* idx
     }
 }
 
-template <typename T>
+// PLAIN: every consumer is MRISR_SP_NONE (17 of the 20 nodes of the U-Net) - compiled without the pool / bilinear
+// adjoint code, whose 32-float windows cost the generic kernel 155 VGPRs = 3 waves per SIMD, too few loads in
+// flight for an HBM-bound pass (measured 3.0 TB/s).
+template <typename T, bool PLAIN>
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams p) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float lds[256 * VEC * 2];
@@ -140,13 +143,14 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
                 const ConsumerDev& cs = p.cons[k];
                 const T* dab = (const T*)cs.da + (size_t)n * cs.H * cs.W * cs.C_total + cs.c_off + c;
                 const float wgt = bw[cs.weight_mode];
-                if (cs.spatial == MRISR_SP_NONE) {
+                if (PLAIN || cs.spatial == MRISR_SP_NONE) {
                     const int yy = y + cs.off_y, xx = x + cs.off_x;
                     if (yy < cs.H && xx < cs.W) {
                         const Vec16<T> d = load_vec16(dab + ((size_t)yy * cs.W + xx) * cs.C_total);
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
                     }
+                } else if constexpr (PLAIN) {
                 } else if (cs.spatial == MRISR_SP_POOL2) {
                     const int py = y >> 1, px = x >> 1;
                     if (py < cs.H && px < cs.W) {
@@ -244,9 +248,16 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     p.pix_per_block = ppblk;
     dim3 grid(ceil_div(HW, ppblk), N);
-    if (dtype == MRISR_BF16) act_bwd_reduce_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else if (dtype == MRISR_F32) act_bwd_reduce_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
+    bool plain = true;
+    for (int k = 0; k < nconsumers; ++k) plain = plain && consumers[k].spatial == MRISR_SP_NONE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) {
+        if (plain) act_bwd_reduce_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p);
+        else act_bwd_reduce_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p);
+    } else if (dtype == MRISR_F32) {
+        if (plain) act_bwd_reduce_kernel<float, true><<<grid, 256, 0, s>>>(p);
+        else act_bwd_reduce_kernel<float, false><<<grid, 256, 0, s>>>(p);
+    } else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("act_bwd_reduce");
     return MRISR_OK;
 }
@@ -333,6 +344,39 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const T* __restrict_
     }
 }
 
+// out_mode PIXEL_SHUFFLE2: dx is stored un-shuffled, [N][H/2][W/2][4C] with channel 4c + 2(Y&1) + (X&1).  Thread =
+// one 16-byte vector of the DESTINATION (VEC/4 source channels x the 2x2 source pixels), so the stores are full
+// vectors; the (n, Y, X, c) -> destination scatter of 2-byte elements ran at a third of the plain kernel's rate.
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_apply_unshuffle_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                                      const float* __restrict__ coef, T* __restrict__ dx,
+                                                                      int N, int H, int W, int C) {
+    constexpr int VEC = Vec16<T>::N, NSC = VEC / 4;      // source channels per thread
+    const int H2 = H / 2, W2 = W / 2, ndv = 4 * C / VEC;
+    const size_t NC = (size_t)N * C;
+    const size_t total = (size_t)N * H2 * W2 * ndv;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int dv = idx % ndv;
+        size_t r = idx / ndv;
+        const int X2 = r % W2; r /= W2;
+        const int Y2 = r % H2;
+        const int n = r / H2;
+        const int c0 = dv * NSC;
+        Vec16<T> o;
+#pragma unroll
+        for (int sc = 0; sc < NSC; ++sc) {
+            const size_t k = (size_t)n * C + c0 + sc;
+            const float cA = coef[k], cB = coef[NC + k], cC = coef[2 * NC + k];
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) {
+                const size_t sp = (((size_t)n * H + 2 * Y2 + (ij >> 1)) * W + 2 * X2 + (ij & 1)) * C + c0 + sc;
+                o.set(4 * sc + ij, to_f32(g[sp]) * cA + to_f32(x[sp]) * cB + cC);
+            }
+        }
+        store_vec16(dx + idx * VEC, o);
+    }
+}
+
 extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N, int H,
                                    int W, int C, int out_mode, void* stream) {
     if (!x || !g || !coef || !dx) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply: null pointer");
@@ -341,6 +385,15 @@ extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, cons
     if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && ((H | W) & 1)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: odd dims with pixel shuffle");
     const size_t total = (size_t)N * H * W * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (4 * C) % vec == 0) {
+        if (dtype == MRISR_BF16)
+            act_bwd_apply_unshuffle_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C);
+        else if (dtype == MRISR_F32)
+            act_bwd_apply_unshuffle_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)g, coef, (float*)dx, N, H, W, C);
+        else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply: dtype %d", dtype);
+        MRISR_CHECK_LAUNCH("act_bwd_apply");
+        return MRISR_OK;
+    }
     if (dtype == MRISR_BF16)
         act_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C, out_mode);
     else if (dtype == MRISR_F32)
@@ -626,16 +679,22 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restr
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
         const T* b = dz + (size_t)n * 4 * h * w * C + cv * VEC;
+        // branch-free: all 16 candidate taps are loaded (coordinates clamped into the image, zero weights for the
+        // ones that do not touch this pixel), row by row, so 4 independent loads are always in flight
 #pragma unroll
         for (int a = 0; a < kUpAdj; ++a) {
-            if (wy[a] == 0.f) continue;
+            const int Y = min(max(iy[a], 0), 2 * h - 1);
+            Vec16<T> d[kUpAdj];
 #pragma unroll
             for (int q = 0; q < kUpAdj; ++q) {
-                if (wx[q] == 0.f) continue;
-                const Vec16<T> d = load_vec16(b + ((size_t)iy[a] * (2 * w) + ix[q]) * C);
+                const int X = min(max(ix[q], 0), 2 * w - 1);
+                d[q] = load_vec16(b + ((size_t)Y * (2 * w) + X) * C);
+            }
+#pragma unroll
+            for (int q = 0; q < kUpAdj; ++q) {
                 const float wv = wy[a] * wx[q];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += wv * d.get(e);
+                for (int e = 0; e < VEC; ++e) acc[e] += wv * d[q].get(e);
             }
         }
         Vec16<T> o;

@@ -408,10 +408,17 @@ class UNetEngine:
                        params["alpha"].data_ptr(), grads["alpha"].data_ptr(), N, layer.H, layer.W, layer.cin, st)
                 a.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 1))
                 b.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 2))
+            elif layer.up_src:
+                # adjoint of the materialised bilinear x2 as its own pass (reads d(aux) once, writes the 4x smaller
+                # low-resolution gradient); the 4x4 gather inside act_bwd_reduce ran at a third of this rate
+                sn = layer.srcs[0].node
+                dlow = torch.empty((N, sn.H, sn.W, layer.cin), dtype=dtype, device=dev)
+                L.call("mrisr_upsample2_adjoint", dt, dain.data_ptr(), dlow.data_ptr(), N, sn.H, sn.W, layer.cin, st)
+                sn.consumers.append((dlow, layer.cin, 0, sn.H, sn.W, L.SP_NONE, 0, 0, 0))
             else:
                 coff = 0
                 for src, (oy, ox) in zip(layer.srcs, layer.offs):
-                    sp = L.SP_POOL2 if layer.pool_src else (L.SP_UP2 if layer.up_src else src.spatial)
+                    sp = L.SP_POOL2 if layer.pool_src else src.spatial
                     src.node.consumers.append((dain, layer.cin, coff, layer.H, layer.W, sp, oy, ox, 0))
                     coff += src.node.C
             if bucket_hook:
