@@ -147,7 +147,8 @@ typedef struct {
 /* backward of LeakyReLU+GroupNorm for one producer tensor x [N][H][W][C] (raw conv output); restates
  * aten leaky_relu_backward + native_group_norm_backward + the adjoints of max_pool2d / upsample_bilinear2d
  * / cat / blend that autograd runs for unet_model.py:30-31,52,71,93,206-207.
- *  reduce  : gathers dL/dact from up to 2 consumers, applies LeakyReLU', writes g = dL/d(gn out) (dtype)
+ *  reduce  : gathers dL/dact from up to 2 consumers, applies LeakyReLU', writes g = dL/d(gn out) (dtype; g may be
+ *            NULL when mrisr_act_bwd_apply_fused is used for pass 2)
  *            and accumulates red[N][C][2] += (sum g, sum g*xhat) (fp32)
  *  finalize: dgamma[C] += sum_n red[..][1], dbeta[C] += sum_n red[..][0], coef[3][N][C] such that
  *            dx = g*coef0 + x*coef1 + coef2      (count = (C/groups)*H*W)
@@ -160,6 +161,11 @@ int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* me
                            float* dbeta, float* coef, int N, int C, int groups, double count, void* stream);
 int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N,
                         int H, int W, int C, int out_mode, void* stream);
+/* apply without the intermediate tensor: when every consumer is MRISR_SP_NONE, mrisr_act_bwd_reduce may be called
+ * with g = NULL and this entry gathers dL/dact from the consumers again (same arguments as the reduce pass).    */
+int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift, int nconsumers,
+                              const mrisr_consumer* consumers, const float* blend_alpha, const float* coef,
+                              void* dx, int N, int H, int W, int C, void* stream);
 /* out[C] += sum over pixels of x[npix][C]  (bias gradient of nn.Conv2d(bias=True), unet_model.py:101) */
 int mrisr_channel_sum(int dtype, const void* x, float* out, size_t npix, int C, void* stream);
 /* dalpha += sigmoid'(alpha) * sum da * (act0 - act1)   (unet_model.py:206-207)               */

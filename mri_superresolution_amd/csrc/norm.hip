@@ -198,11 +198,11 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
                 const float pre = xr * sc[e] + sh[e];
                 const float gy = gact[e] * (pre > 0.f ? 1.f : LRELU_SLOPE);
                 gv.set(e, gy);
-                const float gq = gv.get(e);                 // the rounded value pass 2 will read
+                const float gq = p.g ? gv.get(e) : gy;      // the value pass 2 will use (rounded when it goes through g)
                 sA[e] += gq;
                 sB[e] += gq * ((xr - mean[e]) * rstd[e]);
             }
-            store_vec16(gb + (size_t)pix * p.C + c, gv);
+            if (p.g) store_vec16(gb + (size_t)pix * p.C + c, gv);
         }
     }
     // block reduction over the pixel lanes that share a channel vector
@@ -221,11 +221,54 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
     }
 }
 
+template <typename T>
+__global__ void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef, T* __restrict__ dx);
+
+static int fill_act_bwd_params(ActBwdParams& p, int dtype, int nconsumers, const mrisr_consumer* consumers,
+                               const float* blend_alpha, int H, int W, int C, const char* who) {
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    for (int k = 0; k < nconsumers; ++k) {
+        const mrisr_consumer& c = consumers[k];
+        if (!c.da) MRISR_FAIL(MRISR_E_ARG, "%s: consumer %d null", who, k);
+        if (c.weight_mode < 0 || c.weight_mode > 2 || (c.weight_mode && !blend_alpha)) MRISR_FAIL(MRISR_E_ARG, "%s: weight_mode", who);
+        if (c.c_off % vec || c.C_total % vec || c.c_off + C > c.C_total) MRISR_FAIL(MRISR_E_SHAPE, "%s: consumer %d channels", who, k);
+        if (c.spatial == MRISR_SP_UP2 && (c.off_y + 2 * H > c.H || c.off_x + 2 * W > c.W)) MRISR_FAIL(MRISR_E_SHAPE, "%s: consumer %d UP2 extent", who, k);
+        if (c.spatial == MRISR_SP_POOL2 && (c.H != H / 2 || c.W != W / 2)) MRISR_FAIL(MRISR_E_SHAPE, "%s: consumer %d POOL2 extent", who, k);
+        p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode};
+    }
+    return MRISR_OK;
+}
+
+extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift,
+                                         int nconsumers, const mrisr_consumer* consumers, const float* blend_alpha,
+                                         const float* coef, void* dx, int N, int H, int W, int C, void* stream) {
+    if (!x || !scale || !shift || !coef || !dx || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: null pointer");
+    if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: %d consumers", nconsumers);
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
+    for (int k = 0; k < nconsumers; ++k)
+        if (consumers[k].spatial != MRISR_SP_NONE) MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply_fused: plain consumers only");
+    ActBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.scale = scale; p.shift = shift; p.blend_alpha = blend_alpha;
+    p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C;
+    int rc = fill_act_bwd_params(p, dtype, nconsumers, consumers, blend_alpha, H, W, C, "act_bwd_apply_fused");
+    if (rc) return rc;
+    const size_t total = (size_t)N * H * W * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) act_bwd_apply_fused_kernel<bf16_t><<<blocks, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+    else if (dtype == MRISR_F32) act_bwd_apply_fused_kernel<float><<<blocks, 256, 0, s>>>(p, coef, (float*)dx);
+    else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
+    return MRISR_OK;
+}
+
 extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift,
                                     const float* meanrstd, int nconsumers, const mrisr_consumer* consumers,
                                     const float* blend_alpha, void* g, float* red, int N, int H, int W, int C,
                                     int groups, void* stream) {
-    if (!x || !scale || !shift || !meanrstd || !g || !red || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: null pointer");
+    if (!x || !scale || !shift || !meanrstd || !red || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: null pointer");
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: %d consumers", nconsumers);
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (C % vec || C / vec > 256 || groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: C %d", C);
@@ -341,6 +384,62 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dst[4 * (c + e)] = from_f32<T>(o.get(e));
         }
+    }
+}
+
+// Pass 2 without the intermediate g tensor (plain consumers only): dL/dact is gathered from the consumers again,
+// LeakyReLU' applied, then dx = g*cA + x*cB + cC.  Saves the 2-byte write of pass 1 and reads da instead of g.
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef,
+                                                                  T* __restrict__ dx) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = p.C / VEC;
+    const size_t NC = (size_t)p.N * p.C;
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t total = (size_t)p.N * HW * nvec;
+    float bw[3] = {1.f, 1.f, 1.f};
+    if (p.blend_alpha) {
+        const float a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
+        bw[1] = a;
+        bw[2] = 1.f - a;
+    }
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        const size_t gpix = idx / nvec;
+        const int n = gpix / HW;
+        const int pix = gpix - (size_t)n * HW;
+        const int y = pix / p.W, x = pix - y * p.W;
+        const int c = cv * VEC;
+        const Vec16<T> xv = load_vec16((const T*)p.x + gpix * p.C + c);
+        float gact[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gact[e] = 0.f;
+        for (int k = 0; k < p.ncons; ++k) {
+            const ConsumerDev& cs = p.cons[k];
+            const int yy = y + cs.off_y, xx = x + cs.off_x;
+            if (yy < cs.H && xx < cs.W) {
+                const Vec16<T> d = load_vec16((const T*)cs.da + (((size_t)n * cs.H + yy) * cs.W + xx) * cs.C_total + cs.c_off + c);
+                const float wgt = bw[cs.weight_mode];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
+            }
+        }
+        Vec16<T> o;
+        const size_t k0 = (size_t)n * p.C + c;          // multiple of VEC: 16-byte aligned float4 loads
+#pragma unroll
+        for (int e4 = 0; e4 < VEC; e4 += 4) {
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + k0 + e4), sh4 = *reinterpret_cast<const f32x4*>(p.shift + k0 + e4);
+            const f32x4 ca = *reinterpret_cast<const f32x4*>(coef + k0 + e4), cb = *reinterpret_cast<const f32x4*>(coef + NC + k0 + e4),
+                        cc = *reinterpret_cast<const f32x4*>(coef + 2 * NC + k0 + e4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xr = xv.get(e4 + j);
+                const float pre = xr * sc4[j] + sh4[j];
+                const float gy = gact[e4 + j] * (pre > 0.f ? 1.f : LRELU_SLOPE);
+                o.set(e4 + j, gy * ca[j] + xr * cb[j] + cc[j]);
+            }
+        }
+        store_vec16(dx + gpix * p.C + c, o);
     }
 }
 

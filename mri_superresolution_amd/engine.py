@@ -344,16 +344,25 @@ class UNetEngine:
                 cons[i].C_total, cons[i].c_off, cons[i].H, cons[i].W = ctot, coff, ch, cw
                 cons[i].spatial, cons[i].off_y, cons[i].off_x, cons[i].weight_mode = sp, oy, ox, wm
                 uses_alpha |= wm != 0
-            g = torch.empty_like(n.raw)
+            # plain consumers (no pool gather) and a plain output: pass 2 re-gathers dL/dact instead of going through
+            # a materialised g tensor (one 2-byte write + read per element less)
+            fused = (not n.shuffled) and all(c[5] == L.SP_NONE for c in n.consumers)
+            g = None if fused else torch.empty_like(n.raw)
+            alpha_ptr = params["alpha"].data_ptr() if uses_alpha else None
             red = torch.zeros(N * n.C * 2, dtype=torch.float32, device=dev)
             L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
-                   n.meanrstd.data_ptr(), len(n.consumers), cons,
-                   params["alpha"].data_ptr() if uses_alpha else None, g.data_ptr(), red.data_ptr(),
+                   n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(),
                    N, n.H, n.W, n.C, GN_GROUPS, st)
             coef = torch.empty(3 * N * n.C, dtype=torch.float32, device=dev)
             count = float((n.C // GN_GROUPS) * n.H * n.W)
             L.call("mrisr_act_bwd_finalize", red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
                    grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), coef.data_ptr(), N, n.C, GN_GROUPS, count, st)
+            if fused:
+                dx = torch.empty_like(n.raw)
+                L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                       len(n.consumers), cons, alpha_ptr, coef.data_ptr(), dx.data_ptr(), N, n.H, n.W, n.C, st)
+                n.consumers = []
+                return dx
             if n.shuffled:
                 dx = torch.empty((N, n.H // 2, n.W // 2, 4 * n.C), dtype=dtype, device=dev)
                 mode = L.OUT_PIXEL_SHUFFLE2
