@@ -97,6 +97,14 @@ size_t mrisr_packed_weight_bytes(int dtype, int Cout, int Cin, int ksize);
  * (roles of Cin/Cout swapped, taps mirrored).                                              */
 int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, int ksize, int transpose_flip,
                        void* packed, void* stream);
+/* the same for many weights in ONE launch (a training step re-packs every layer after the optimiser update):
+ * jobs_device = device array of njobs descriptors (pointers as in mrisr_pack_weights)                          */
+typedef struct {
+    const float* w;
+    void* packed;
+    int32_t Cout, Cin, ksize, transpose_flip;
+} mrisr_pack_job;
+int mrisr_pack_weights_batched(int dtype, const mrisr_pack_job* jobs_device, int njobs, void* stream);
 int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream);
 /* writes the name of the kernel instantiation mrisr_conv_forward (wgrad=0) / mrisr_conv_wgrad (wgrad=1) will
  * launch for this descriptor, template arguments as in the mangled symbol rocprofv3 reports               */

@@ -32,6 +32,11 @@ class ConvDesc(C.Structure):
                 ("bias", _fp), ("out", _vp), ("stats", _dp), ("relu_mask", _vp)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", _fp), ("packed", _vp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32),
+                ("transpose_flip", C.c_int32)]
+
+
 class Consumer(C.Structure):
     _fields_ = [("da", _vp), ("C_total", C.c_int32), ("c_off", C.c_int32), ("H", C.c_int32),
                 ("W", C.c_int32), ("spatial", C.c_int32), ("off_y", C.c_int32), ("off_x", C.c_int32),
@@ -44,6 +49,7 @@ SIGNATURES = {
     "mrisr_version": (_i, []),
     "mrisr_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mrisr_pack_weights": (_i, [_i, _fp, _i, _i, _i, _i, _vp, _vp]),
+    "mrisr_pack_weights_batched": (_i, [_i, _vp, _i, _vp]),
     "mrisr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "mrisr_conv_variant": (_i, [C.POINTER(ConvDesc), _i, C.c_char_p, _sz]),
     "mrisr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _fp, _vp]),

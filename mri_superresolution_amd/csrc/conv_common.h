@@ -27,6 +27,14 @@ static inline size_t conv_halo_bytes() { return (size_t)kMaxHaloIter * 64 * kHal
 static inline bool conv_weights_stationary(int nchunks, size_t wimg) {
     return nchunks * wimg + 2 * conv_halo_bytes() + 64 * sizeof(float) <= 158 * 1024;
 }
+// wgrad kernel variant: 0 = generic, 1 / 2 / 4 = FAST with that k-step interleave (bf16 3x3 plain loader, 8x32 tiles,
+// every channel block of the launch holding the same number of 32x32 fragment pairs)
+static inline int conv_wgrad_fast(int dtype, int loader, int ks, int tw_log2, int Cout, int Cin) {
+    if (dtype != MRISR_BF16 || loader != MRISR_SP_NONE || ks != 3 || tw_log2 != 5) return 0;
+    const int nfo = Cout % 64 == 0 ? 2 : (Cout <= 32 ? 1 : 0), nfi = Cin % 64 == 0 ? 2 : (Cin <= 32 ? 1 : 0);
+    if (!nfo || !nfi) return 0;
+    return 4 / (nfo * nfi);
+}
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
 static inline int conv_bk(int dtype) { return dtype == MRISR_BF16 ? 32 : 16; }
 

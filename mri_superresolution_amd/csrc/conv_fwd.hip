@@ -515,6 +515,54 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     }
 }
 
+// All layers of a model in one launch (the optimiser rewrites every master weight each step): blockIdx.y = job.
+struct PackJobDev { const float* w; void* packed; int Cout, Cin, ksize, flip; };
+template <typename T>
+__global__ void pack_weights_batched_kernel(const PackJobDev* __restrict__ jobs) {
+    constexpr int BK = kRowBytes / (int)sizeof(T);
+    const PackJobDev j = jobs[blockIdx.y];
+    const int KS = j.ksize, ntaps = KS * KS, Cin = j.Cin, Cout = j.Cout, flip = j.flip;
+    const int Co = flip ? Cin : Cout, Ci = flip ? Cout : Cin;   // logical (output, input) of the image
+    const int BN = Co >= 64 ? 64 : 32;                          // conv_choose_bn
+    const int ncb = (Co + BN - 1) / BN, nchunks = (Ci + BK - 1) / BK;
+    const size_t total = (size_t)ncb * nchunks * ntaps * BN * BK;
+    const float* __restrict__ w = j.w;
+    T* __restrict__ out = (T*)j.packed;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int e = r % BK; r /= BK;
+        const int row = r % BN; r /= BN;
+        const int tap = r % ntaps; r /= ntaps;
+        const int kc = r % nchunks;
+        const int cb = r / nchunks;
+        constexpr int EPC = 16 / (int)sizeof(T);
+        const int q = tap * BN + row;
+        const int chunk_pos = e / EPC, chunk = chunk_pos ^ ((q >> 2) & 3);
+        const int k = kc * BK + chunk * EPC + (e % EPC);
+        const int co = cb * BN + row;
+        float v = 0.f;
+        if (co < Co && k < Ci) {
+            if (!flip) v = w[((size_t)co * ntaps + tap) * Cin + k];
+            else v = w[((size_t)k * ntaps + (ntaps - 1 - tap)) * Cin + co];
+        }
+        out[idx] = from_f32<T>(v);
+    }
+}
+
+extern "C" int mrisr_pack_weights_batched(int dtype, const mrisr_pack_job* jobs_device, int njobs, void* stream) {
+    static_assert(sizeof(PackJobDev) == sizeof(mrisr_pack_job), "mrisr_pack_job layout");
+    if (!jobs_device || njobs <= 0 || njobs > 65535) MRISR_FAIL(MRISR_E_ARG, "pack_weights_batched: bad job table");
+    dim3 grid(48, njobs);
+    if (dtype == MRISR_BF16)
+        pack_weights_batched_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const PackJobDev*)jobs_device);
+    else if (dtype == MRISR_F32)
+        pack_weights_batched_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const PackJobDev*)jobs_device);
+    else
+        MRISR_FAIL(MRISR_E_DTYPE, "pack_weights_batched: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("pack_weights_batched");
+    return MRISR_OK;
+}
+
 extern "C" size_t mrisr_packed_weight_bytes(int dtype, int Cout, int Cin, int ksize) {
     const int BN = conv_choose_bn(Cout), BK = conv_bk(dtype);
     const size_t ncb = ceil_div(Cout, BN), nch = ceil_div(Cin, BK);
@@ -689,7 +737,8 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     const char* t = d->dtype == MRISR_BF16 ? "bf16" : "f32";
     const int loader = d->combine == MRISR_COMBINE_BLEND ? 3 : d->src[0].spatial;
     if (wgrad) {
-        snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d>", t, loader, d->ksize);
+        snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d,%d>", t, loader, d->ksize,
+                 conv_wgrad_fast(d->dtype, loader, d->ksize, p.tw_log2, d->Cout, d->Cin));
     } else {
         const int BN = conv_choose_bn(d->Cout);
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;

@@ -40,10 +40,11 @@ __device__ __forceinline__ bf16x8 tr_read_frag(const char* base0, const char* ba
 
 constexpr int kLoaderBlendW = 3;     // template-only loader kind: sigmoid(alpha)-blend of two sources
 
-// FAST: bf16 3x3, 8x32 tiles, Cout and Cin multiples of 64 (every wave owns a full 32x32 fragment pair): only the
-// fully unrolled immediate-offset MFMA block is compiled in (the generic block's hoisted address pieces would
+// FAST = 1, 2 or 4 (0 = generic): bf16 3x3, 8x32 tiles, every channel block of the launch holding the same number of
+// 32x32 fragment pairs (4 / FAST: Cout and Cin each a multiple of 64 or <= 32); FAST = k-step interleave of the waves
+// that share a pair.  Only the fully unrolled immediate-offset MFMA block is compiled in (the generic block's hoisted address pieces would
 // otherwise push this variant over the register budget).
-template <typename T, int SPATIAL, int KS, bool FAST = false>
+template <typename T, int SPATIAL, int KS, int FAST = 0>
 __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams p = pin_params(p_in);
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     const int nfi = kBf16 ? (min(p.Cin - ci0, BC) > 32 ? 2 : 1) : 1;
     const int npairs = nfo * nfi, kparts = 4 / npairs;        // 1, 2 or 4 pairs
     const int pair = (wave & 3) % npairs, kpart = (wave & 3) / npairs;
+    const int kpartu = __builtin_amdgcn_readfirstlane(kpart);
     const int fo = pair / nfi, fi = pair % nfi;
     f32x16 acc[NT0];
 #pragma unroll
@@ -266,14 +268,22 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     auto mfma_fast = [&](auto tg_tag) {
         constexpr int TG = decltype(tg_tag)::value;
         constexpr int HWC = 32 + 2 * PAD;
+        constexpr int KP = FAST > 0 ? FAST : 1;           // this wave takes k-steps kpart, kpart + KP, ...
         constexpr int NTG = TG ? NTAPS - NT0 : NT0;       // taps of this group
-        constexpr int NS = 16 * NTG;                      // (k-step, tap) steps, one MFMA each
+        constexpr int NS = (16 / KP) * NTG;               // (k-step, tap) steps, one MFMA each
         const char* bufp = smem + cur * buf_bytes;
-        const char* ab = bufp + a_lane;
-        const char* bb[4] = {bufp + b_lane[0], bufp + b_lane[1], bufp + b_lane[2], bufp + b_lane[3]};
-        auto load_a = [&](int ks) { return tr_read_frag(ab + ks * 2048, ab + ks * 2048 + 512); };
+        // wave part of the halo row K (k-step offset kpart): folded into the bases; it also rotates the swizzle class
+        const int kw = KP == 2 ? kpartu * 16 : (KP == 4 ? (kpartu >> 1) * HWC + (kpartu & 1) * 16 : 0);
+        const char* ab = bufp + a_lane + kpartu * 2048;
+        const char* bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cls = (j + kw) & 3;      // scalar
+            bb[j] = bufp + kw * 128 + (cls == 0 ? b_lane[0] : cls == 1 ? b_lane[1] : cls == 2 ? b_lane[2] : b_lane[3]);
+        }
+        auto load_a = [&](int i) { return tr_read_frag(ab + i * KP * 2048, ab + i * KP * 2048 + 512); };
         auto load_b = [&](int st) {
-            const int ks = st / NTG, tap = (TG ? NT0 : 0) + st % NTG;
+            const int ks = (st / NTG) * KP, tap = (TG ? NT0 : 0) + st % NTG;
             const int K = (ks >> 1) * HWC + (ks & 1) * 16 + (tap / KS) * HWC + (tap % KS);
             const char* b = bb[K & 3] + K * 128;
             return tr_read_frag(b, b + 512);
@@ -286,11 +296,11 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         bq[1] = load_b(1);
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            const int ks = st / NTG, j = st % NTG;
+            const int i = st / NTG, j = st % NTG;
             if (st + 2 < NS) bq[(st + 2) % 3] = load_b(st + 2);
-            if (j == 0 && ks + 1 < 16) aq[(ks + 1) & 1] = load_a(ks + 1);
+            if (j == 0 && (i + 1) * KP < 16) aq[(i + 1) & 1] = load_a(i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1], bq[st % 3], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i & 1], bq[st % 3], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who);
 int num_cus();
 
-template <typename T, int SPATIAL, int KS, bool FAST = false>
+template <typename T, int SPATIAL, int KS, int FAST = 0>
 static int launch_wgrad(ConvParams& p, hipStream_t s) {
     constexpr int BC = WgTraits<T>::BC;
     const int TW = 1 << p.tw_log2, pad = KS / 2;
@@ -418,8 +428,10 @@ static int dispatch_wgrad(ConvParams& p, int spatial, int ks, hipStream_t s) {
     }
     if (ks == 3) {
         if constexpr (sizeof(T) == 2) {
-            if (spatial == MRISR_SP_NONE && p.tw_log2 == 5 && p.Cout % 64 == 0 && p.Cin % 64 == 0)
-                return launch_wgrad<T, MRISR_SP_NONE, 3, true>(p, s);
+            const int fast = conv_wgrad_fast(MRISR_BF16, spatial, 3, p.tw_log2, p.Cout, p.Cin);
+            if (fast == 1) return launch_wgrad<T, MRISR_SP_NONE, 3, 1>(p, s);
+            if (fast == 2) return launch_wgrad<T, MRISR_SP_NONE, 3, 2>(p, s);
+            if (fast == 4) return launch_wgrad<T, MRISR_SP_NONE, 3, 4>(p, s);
         }
         if (spatial == MRISR_SP_NONE) return launch_wgrad<T, MRISR_SP_NONE, 3>(p, s);
         if (spatial == MRISR_SP_POOL2) return launch_wgrad<T, MRISR_SP_POOL2, 3>(p, s);

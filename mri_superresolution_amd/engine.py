@@ -189,6 +189,42 @@ class UNetEngine:
             self._pack_versions[key] = ver
         return buf
 
+    def invalidate_packed(self):
+        """Forget every packed weight image (the parameter storage moved or was replaced)."""
+        self._packed.clear()
+        self._pack_versions.clear()
+        self._jobs_key = None
+
+    def _pack_all(self, params, dt: int, stream):
+        """Training: every conv weight (forward and mirrored dgrad image) re-packed in ONE launch per step."""
+        dev = params[self.layers[0].name + ".weight"].device
+        key = (dt, str(dev), tuple(params[l.name + ".weight"].data_ptr() for l in self.layers))
+        if getattr(self, "_jobs_key", None) != key:
+            jobs = (L.PackJob * (2 * len(self.layers)))()
+            i = 0
+            for layer in self.layers:
+                w = params[layer.name + ".weight"]
+                for flip in (0, 1):
+                    k = (layer.name, dt, flip)
+                    buf = self._packed.get(k)
+                    if buf is None or buf.device != w.device:
+                        nbytes = L.load().mrisr_packed_weight_bytes(dt, layer.cin if flip else layer.cout,
+                                                                    layer.cout if flip else layer.cin, layer.ks)
+                        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+                        self._packed[k] = buf
+                    j = jobs[i]
+                    j.w, j.packed, j.Cout, j.Cin, j.ksize, j.transpose_flip = w.data_ptr(), buf.data_ptr(), layer.cout, layer.cin, layer.ks, flip
+                    i += 1
+            host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+            self._jobs_dev = host.to(dev)
+            self._jobs_n = i
+            self._jobs_key = key
+        L.call("mrisr_pack_weights_batched", dt, self._jobs_dev.data_ptr(), self._jobs_n, stream)
+        for layer in self.layers:
+            w = params[layer.name + ".weight"]
+            for flip in (0, 1):
+                self._pack_versions[(layer.name, dt, flip)] = (w.data_ptr(), w._version)
+
     # ------------------------------------------------------------------ descriptors
     def _desc(self, layer: Layer, dt: int, N: int, params) -> L.ConvDesc:
         d = L.ConvDesc()
@@ -247,6 +283,8 @@ class UNetEngine:
                    n.scale.data_ptr(), n.shift.data_ptr(), n.meanrstd.data_ptr(), N, n.C, GN_GROUPS, count,
                    GN_EPS, st)
 
+        if training:      # the optimiser rewrites the masters through raw pointers every step -> always repack
+            self._pack_all(params, dt, st)
         # stem
         s = self.stem
         s.N, s.H, s.W = N, H, W
@@ -287,7 +325,7 @@ class UNetEngine:
             o.raw = torch.empty((N, o.H, o.W, o.C), dtype=dtype, device=dev)
             d = self._desc(layer, dt, N, params)
             # training: the optimiser rewrites the masters through raw pointers every step -> always repack
-            d.wpacked = self._packed_weight(layer, params, dt, 0, st, force=training).data_ptr()
+            d.wpacked = self._packed_weight(layer, params, dt, 0, st).data_ptr()
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
             if layer.post_up:
                 zlow = torch.empty((N, vh, vw, o.C), dtype=dtype, device=dev)
@@ -335,6 +373,15 @@ class UNetEngine:
             l.H, l.W, l.offs, l.aux = ctx["layers"][l.name]
         dout = dout.contiguous()
 
+        # one zero-filled arena for the per-node (sum g, sum g*xhat) buffers instead of 20 small fills
+        red_sizes = [N * n.C * 2 for n in self.nodes.values()]
+        red_arena = torch.zeros(sum(red_sizes), dtype=torch.float32, device=dev)
+        red_off = {}
+        o = 0
+        for n, sz in zip(self.nodes.values(), red_sizes):
+            red_off[n.name] = (o, sz)
+            o += sz
+
         def node_backward(n: Node) -> torch.Tensor:
             """dL/dact (gathered from consumers) -> dL/d(raw conv output), plus GN affine grads."""
             cons = (L.Consumer * 2)()
@@ -349,7 +396,7 @@ class UNetEngine:
             fused = (not n.shuffled) and all(c[5] == L.SP_NONE for c in n.consumers)
             g = None if fused else torch.empty_like(n.raw)
             alpha_ptr = params["alpha"].data_ptr() if uses_alpha else None
-            red = torch.zeros(N * n.C * 2, dtype=torch.float32, device=dev)
+            red = red_arena[red_off[n.name][0]:red_off[n.name][0] + red_off[n.name][1]]
             L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
                    n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(),
                    N, n.H, n.W, n.C, GN_GROUPS, st)
@@ -406,7 +453,7 @@ class UNetEngine:
             dd.src[0].ptr = dy.data_ptr()
             dd.src[0].C, dd.src[0].H, dd.src[0].W = layer.cout, layer.H, layer.W
             dd.src[0].mode, dd.src[0].spatial = L.SRC_RAW, L.SP_NONE
-            dd.wpacked = self._packed_weight(layer, params, dt, 1, st, force=True).data_ptr()
+            dd.wpacked = self._packed_weight(layer, params, dt, 1, st).data_ptr()
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
             self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))

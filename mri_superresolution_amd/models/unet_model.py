@@ -203,8 +203,7 @@ class UNetSuperRes(nn.Module):
                 off += sz
         self.flat_params, self.flat_grads = flat, grads
         self._grad_hook = torch.zeros(1, device=dev, requires_grad=True)
-        self._engine._packed.clear()
-        self._engine._pack_versions.clear()
+        self._engine.invalidate_packed()
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn, recurse)

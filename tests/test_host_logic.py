@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     from mri_superresolution_amd import _lib
     hdr = open(os.path.join(REPO, "include", "mrisr.h")).read()
     declared = set(re.findall(r"\b(mrisr_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"mrisr_src", "mrisr_conv_desc", "mrisr_consumer"}
+    declared -= {"mrisr_src", "mrisr_conv_desc", "mrisr_consumer", "mrisr_pack_job"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().mrisr_pack_weights(0, None, 8, 8, 3, 0, None, None) == -1
     assert b"null" in _lib.load().mrisr_last_error()
     # struct layouts match the header (sizes as compiled by the C side are fixed by the field lists)
-    assert ctypes.sizeof(_lib.Src) == 56 and ctypes.sizeof(_lib.Consumer) == 40
+    assert ctypes.sizeof(_lib.Src) == 56 and ctypes.sizeof(_lib.Consumer) == 40 and ctypes.sizeof(_lib.PackJob) == 32
 
 
 def test_module_contract_matches_reference_spec():

@@ -21,10 +21,10 @@ def demangle_conv(name):
     if m:
         t = "bf16" if m.group(1) == "DF16b" else "f32"
         return f"conv_igemm_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}>"
-    m = re.match(r"_Z17conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)EEv10ConvParams", name)
+    m = re.match(r"_Z17conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv10ConvParams", name)
     if m:
         t = "bf16" if m.group(1) == "DF16b" else "f32"
-        return f"conv_wgrad_kernel<{t},{m.group(2)},{m.group(3)}>"
+        return f"conv_wgrad_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)}>"
     return re.sub(r"\(.*", "", name)
 
 
