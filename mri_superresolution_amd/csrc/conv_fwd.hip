@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     const float qq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
                     st_s[ni][q] = fmaf(pvf, qs, st_s[ni][q]);
                     st_ss[ni][q] = fmaf(pvf, qq, st_ss[ni][q]);
-                    if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
+                    if constexpr (sizeof(T) == 2) {   // bf16: packed, stored after the lane exchange below
                         union { bf16x4 b; u32x2 u; } cv;
                         cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         packed[q] = cv.u;
@@ -406,6 +406,28 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                             }
                             gstore(outp + pix * p.Cout + co8, o);
                         }
+                    }
+                }
+                if constexpr (EPI == MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
+                    // PixelShuffle(2): conv channel 4c'+2i+j -> pixel (2y+i, 2x+j), channel c'.  packed[q] = the four
+                    // (i,j) values of c' = cb + 2q + lh.  For one (i,j): this lane holds c' = cb + {0,2,4,6} + lh; one
+                    // permlane32 swap + a 16-bit interleave give the low half c' = cb..cb+3 and the high half
+                    // cb+4..cb+7 -> one 8-byte store per (i,j) instead of four 2-byte stores.
+                    const int C4 = p.Cout >> 2, cb = (bn0 + ni * 32) >> 2;
+                    const bool okc = cb + 4 * lh < C4;                 // (C4 % 4 == 0: host-checked for this epilogue)
+#pragma unroll
+                    for (int ij = 0; ij < 4; ++ij) {
+                        // 16-bit element ij of packed[q]: dword ij>>1, half ij&1
+                        auto pick = [&](int qa, int qb) {   // bf16x2 {c'(qa), c'(qb)} of this (i,j)
+                            const unsigned a = packed[qa][ij >> 1], b = packed[qb][ij >> 1];
+                            return (ij & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                        };
+                        const unsigned P0 = pick(0, 1), P1 = pick(2, 3);          // own c' = {0,2}+lh and {4,6}+lh
+                        auto r = __builtin_amdgcn_permlane32_swap(P0, P1, false, false);   // P0.hi-lanes <-> P1.lo-lanes
+                        const unsigned X = r[0], Y = r[1];   // low half: X={0,2} Y={1,3}; high half: X={4,6} Y={5,7}
+                        const u32x2 o = {(X & 0xffffu) | (Y << 16), (X >> 16) | (Y & 0xffff0000u)};
+                        if (pv && okc && !(p.dbg & 1))
+                            gstore(outp + ((size_t)(n * 2 * p.H + 2 * oy + (ij >> 1)) * (2 * p.W) + 2 * ox + (ij & 1)) * C4 + cb + 4 * lh, o);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // bound the scheduling window: one (mi, ni) group's temporaries live at a time
@@ -552,7 +574,7 @@ __global__ void pack_weights_batched_kernel(const PackJobDev* __restrict__ jobs)
 extern "C" int mrisr_pack_weights_batched(int dtype, const mrisr_pack_job* jobs_device, int njobs, void* stream) {
     static_assert(sizeof(PackJobDev) == sizeof(mrisr_pack_job), "mrisr_pack_job layout");
     if (!jobs_device || njobs <= 0 || njobs > 65535) MRISR_FAIL(MRISR_E_ARG, "pack_weights_batched: bad job table");
-    dim3 grid(48, njobs);
+    dim3 grid(256, njobs);     // small jobs leave their surplus blocks immediately; the largest image decides the time
     if (dtype == MRISR_BF16)
         pack_weights_batched_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const PackJobDev*)jobs_device);
     else if (dtype == MRISR_F32)
@@ -754,7 +776,7 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     int rc = conv_fill_params(d, p, "conv_forward");
     if (rc) return rc;
     if (!d->wpacked || !d->out) MRISR_FAIL(MRISR_E_ARG, "conv_forward: null weights/out");
-    if (d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (d->Cout % 4)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: pixel shuffle needs Cout%%4==0");
+    if (d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (d->Cout % 16)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: pixel shuffle needs Cout%%16==0");
     if (d->relu_mask && (d->out_mode != MRISR_OUT_PLAIN || d->Cout % (d->dtype == MRISR_BF16 ? 8 : 4)))
         MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask needs a plain output with Cout a multiple of the 16-byte vector");
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);

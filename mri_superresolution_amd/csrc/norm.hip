@@ -64,6 +64,7 @@ struct ActBwdParams {
     float* red;      // [N][C][2]
     ConsumerDev cons[2];
     int ncons, N, H, W, C, groups, pix_per_block;
+    int nvec_shift;  // log2(C / VEC) when that is a power of two, else -1
 };
 
 template <typename T>
@@ -96,8 +97,9 @@ __device__ __forceinline__ void up2_adjoint_weights(int y, int in_size, int* idx
 // PLAIN: every consumer is MRISR_SP_NONE (17 of the 20 nodes of the U-Net) - compiled without the pool / bilinear
 // adjoint code, whose 32-float windows cost the generic kernel 155 VGPRs = 3 waves per SIMD, too few loads in
 // flight for an HBM-bound pass (measured 3.0 TB/s).
-template <typename T, bool PLAIN>
+template <typename T, int KIND>   // 0: plain consumers only, 1: plain + 2x2 max-pool, 2: + bilinear adjoint gather
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams p) {
+    constexpr bool PLAIN = KIND == 0;
     constexpr int VEC = Vec16<T>::N;
     __shared__ float lds[256 * VEC * 2];
     const int t = threadIdx.x, n = blockIdx.y;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
             for (int k = 0; k < p.ncons; ++k) {
                 const ConsumerDev& cs = p.cons[k];
                 const T* dab = (const T*)cs.da + (size_t)n * cs.H * cs.W * cs.C_total + cs.c_off + c;
-                const float wgt = bw[cs.weight_mode];
+                const float wgt = cs.weight_mode == 0 ? 1.f : (cs.weight_mode == 1 ? bw[1] : bw[2]);
                 if (PLAIN || cs.spatial == MRISR_SP_NONE) {
                     const int yy = y + cs.off_y, xx = x + cs.off_x;
                     if (yy < cs.H && xx < cs.W) {
@@ -154,24 +156,28 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
                 } else if (cs.spatial == MRISR_SP_POOL2) {
                     const int py = y >> 1, px = x >> 1;
                     if (py < cs.H && px < cs.W) {
-                        // recompute the 2x2 window's activations; the first maximum in scan order wins
-                        float a[4][VEC];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            act_of<T>(xb + ((size_t)(2 * py + (q >> 1)) * p.W + 2 * px + (q & 1)) * p.C + c, sc, sh, a[q]);
+                        // recompute the 2x2 window's activations one at a time (two 8-float sets live instead of
+                        // five): this pixel wins iff it beats every EARLIER window element strictly and every
+                        // later one weakly - aten's scan keeps the first maximum
                         const int me = ((y & 1) << 1) | (x & 1);
+                        float am[VEC];
+                        bool win[VEC];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) { am[e] = lrelu(xv.get(e) * sc[e] + sh[e]); win[e] = true; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q == me) continue;
+                            float aq[VEC];
+                            act_of<T>(xb + ((size_t)(2 * py + (q >> 1)) * p.W + 2 * px + (q & 1)) * p.C + c, sc, sh, aq);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) win[e] = win[e] && (q < me ? aq[e] < am[e] : aq[e] <= am[e]);
+                        }
                         const Vec16<T> d = load_vec16(dab + ((size_t)py * cs.W + px) * cs.C_total);
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            int win = 0;
-                            float m = a[0][e];
-#pragma unroll
-                            for (int q = 1; q < 4; ++q)
-                                if (a[q][e] > m) { m = a[q][e]; win = q; }
-                            if (win == me) gact[e] += wgt * d.get(e);
-                        }
+                        for (int e = 0; e < VEC; ++e)
+                            if (win[e]) gact[e] += wgt * d.get(e);
                     }
-                } else {   // adjoint of bilinear x2 (align_corners=True)
+                } else if constexpr (KIND == 2) {   // adjoint of bilinear x2 (align_corners=True)
                     int iy[kUpAdj], ix[kUpAdj];
                     float wy[kUpAdj], wx[kUpAdj];
                     up2_adjoint_weights(y, p.H, iy, wy);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
     }
 }
 
-template <typename T>
+template <typename T, bool SAME>
 __global__ void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef, T* __restrict__ dx);
 
 static int fill_act_bwd_params(ActBwdParams& p, int dtype, int nconsumers, const mrisr_consumer* consumers,
@@ -257,9 +263,20 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     const size_t total = (size_t)N * H * W * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MRISR_BF16) act_bwd_apply_fused_kernel<bf16_t><<<blocks, 256, 0, s>>>(p, coef, (bf16_t*)dx);
-    else if (dtype == MRISR_F32) act_bwd_apply_fused_kernel<float><<<blocks, 256, 0, s>>>(p, coef, (float*)dx);
-    else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
+    bool same = true;
+    for (int k = 0; k < nconsumers; ++k)
+        same = same && consumers[k].H == H && consumers[k].W == W && consumers[k].off_y == 0 && consumers[k].off_x == 0;
+    const int nvec = C / vec;
+    p.nvec_shift = -1;
+    for (int sft = 0; sft < 16; ++sft)
+        if ((1 << sft) == nvec) p.nvec_shift = sft;
+    if (dtype == MRISR_BF16) {
+        if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<blocks, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+        else act_bwd_apply_fused_kernel<bf16_t, false><<<blocks, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+    } else if (dtype == MRISR_F32) {
+        if (same) act_bwd_apply_fused_kernel<float, true><<<blocks, 256, 0, s>>>(p, coef, (float*)dx);
+        else act_bwd_apply_fused_kernel<float, false><<<blocks, 256, 0, s>>>(p, coef, (float*)dx);
+    } else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
     return MRISR_OK;
 }
@@ -291,15 +308,20 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     p.pix_per_block = ppblk;
     dim3 grid(ceil_div(HW, ppblk), N);
-    bool plain = true;
-    for (int k = 0; k < nconsumers; ++k) plain = plain && consumers[k].spatial == MRISR_SP_NONE;
+    int kind = 0;
+    for (int k = 0; k < nconsumers; ++k) {
+        if (consumers[k].spatial == MRISR_SP_POOL2 && kind < 1) kind = 1;
+        if (consumers[k].spatial == MRISR_SP_UP2) kind = 2;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MRISR_BF16) {
-        if (plain) act_bwd_reduce_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p);
-        else act_bwd_reduce_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p);
+        if (kind == 0) act_bwd_reduce_kernel<bf16_t, 0><<<grid, 256, 0, s>>>(p);
+        else if (kind == 1) act_bwd_reduce_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p);
+        else act_bwd_reduce_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p);
     } else if (dtype == MRISR_F32) {
-        if (plain) act_bwd_reduce_kernel<float, true><<<grid, 256, 0, s>>>(p);
-        else act_bwd_reduce_kernel<float, false><<<grid, 256, 0, s>>>(p);
+        if (kind == 0) act_bwd_reduce_kernel<float, 0><<<grid, 256, 0, s>>>(p);
+        else if (kind == 1) act_bwd_reduce_kernel<float, 1><<<grid, 256, 0, s>>>(p);
+        else act_bwd_reduce_kernel<float, 2><<<grid, 256, 0, s>>>(p);
     } else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("act_bwd_reduce");
     return MRISR_OK;
@@ -389,7 +411,9 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const T* __restrict_
 
 // Pass 2 without the intermediate g tensor (plain consumers only): dL/dact is gathered from the consumers again,
 // LeakyReLU' applied, then dx = g*cA + x*cB + cC.  Saves the 2-byte write of pass 1 and reads da instead of g.
-template <typename T>
+// SAME: every consumer gradient has the node's own H x W and no pad offset (all but the odd-size decoder nodes): the
+// consumer element is addressed by the linear pixel index - no div/mod per element.
+template <typename T, bool SAME>
 __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef,
                                                                   T* __restrict__ dx) {
     constexpr int VEC = Vec16<T>::N;
@@ -403,25 +427,43 @@ __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdPa
         bw[1] = a;
         bw[2] = 1.f - a;
     }
+    const int m0 = p.cons[0].weight_mode, m1 = p.cons[1].weight_mode;
+    const float w0 = m0 == 0 ? 1.f : (m0 == 1 ? bw[1] : bw[2]), w1 = m1 == 0 ? 1.f : (m1 == 1 ? bw[1] : bw[2]);
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int cv = idx % nvec;
-        const size_t gpix = idx / nvec;
-        const int n = gpix / HW;
-        const int pix = gpix - (size_t)n * HW;
-        const int y = pix / p.W, x = pix - y * p.W;
+        int cv;
+        size_t gpix;
+        if (p.nvec_shift >= 0) { cv = (int)(idx & (nvec - 1)); gpix = idx >> p.nvec_shift; }
+        else { cv = idx % nvec; gpix = idx / nvec; }
         const int c = cv * VEC;
         const Vec16<T> xv = load_vec16((const T*)p.x + gpix * p.C + c);
         float gact[VEC];
+        int n;
+        if constexpr (SAME) {
+            const Vec16<T> d0 = load_vec16((const T*)p.cons[0].da + gpix * p.cons[0].C_total + p.cons[0].c_off + c);
+            if (p.ncons > 1) {
+                const Vec16<T> d1 = load_vec16((const T*)p.cons[1].da + gpix * p.cons[1].C_total + p.cons[1].c_off + c);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) gact[e] = 0.f;
-        for (int k = 0; k < p.ncons; ++k) {
-            const ConsumerDev& cs = p.cons[k];
-            const int yy = y + cs.off_y, xx = x + cs.off_x;
-            if (yy < cs.H && xx < cs.W) {
-                const Vec16<T> d = load_vec16((const T*)cs.da + (((size_t)n * cs.H + yy) * cs.W + xx) * cs.C_total + cs.c_off + c);
-                const float wgt = bw[cs.weight_mode];
+                for (int e = 0; e < VEC; ++e) gact[e] = w0 * d0.get(e) + w1 * d1.get(e);
+            } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
+                for (int e = 0; e < VEC; ++e) gact[e] = w0 * d0.get(e);
+            }
+            n = (int)(gpix / HW);
+        } else {
+            n = (int)(gpix / HW);
+            const int pix = (int)(gpix - (size_t)n * HW);
+            const int y = pix / p.W, x = pix - y * p.W;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gact[e] = 0.f;
+            for (int k = 0; k < p.ncons; ++k) {
+                const ConsumerDev& cs = p.cons[k];
+                const int yy = y + cs.off_y, xx = x + cs.off_x;
+                if (yy < cs.H && xx < cs.W) {
+                    const Vec16<T> d = load_vec16((const T*)cs.da + (((size_t)n * cs.H + yy) * cs.W + xx) * cs.C_total + cs.c_off + c);
+                    const float wgt = cs.weight_mode == 0 ? 1.f : (cs.weight_mode == 1 ? bw[1] : bw[2]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
+                }
             }
         }
         Vec16<T> o;

@@ -67,7 +67,8 @@ def main():
         keep = []
         d = L.ConvDesc()
         d.dtype, d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.nsrc = dt, N, H, W, cin, cout, ks, nsrc
-        d.combine, d.out_mode, d.groups = comb, L.OUT_PLAIN, 8
+        # final_up_pixelshuffle.conv stores through the pixel-shuffle epilogue (same bytes, other layout)
+        d.combine, d.out_mode, d.groups = comb, (L.OUT_PIXEL_SHUFFLE2 if name == "fin.ps" else L.OUT_PLAIN), 8
         csrc = cin if comb == L.COMBINE_BLEND else cin // nsrc
         for i in range(nsrc):
             hs = {L.SP_NONE: H, L.SP_POOL2: 2 * H, L.SP_UP2: H // 2}[sp if i == 0 else L.SP_NONE]
