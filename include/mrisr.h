@@ -133,6 +133,11 @@ int mrisr_norm_pool2(int dtype, const void* x, const float* scale, const float* 
  * final_up_bilinear's 3x3 conv (unet_model.py:151-152).                                                     */
 int mrisr_norm_upsample2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
                          int h, int w, int C, void* stream);
+/* out [N][H][W][C] = sigmoid(alpha)*LeakyReLU(x0*scale0+shift0) + (1-sigmoid(alpha))*LeakyReLU(x1*scale1+shift1): the
+ * materialised alpha blend of the two head branches (unet_model.py:206-207), input of final_conv.0.               */
+int mrisr_norm_blend(int dtype, const void* x0, const float* scale0, const float* shift0, const void* x1,
+                     const float* scale1, const float* shift1, const float* alpha, void* out, int N, int H, int W,
+                     int C, void* stream);
 /* z [N][2h][2w][C] = bilinear x2 (align_corners=True) of z_low [N][h][w][C], plus GroupNorm statistics of z
  * (stats [N][groups][2] double, accumulated; may be NULL).  With mrisr_conv_forward on the low-resolution
  * tensor this evaluates nn.Upsample -> nn.Conv2d(1x1) (unet_model.py:71-72) as conv -> upsample.           */

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mrisr_gn_finalize": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _f, _vp]),
     "mrisr_norm_pool2": (_i, [_i, _vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_norm_upsample2": (_i, [_i, _vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    "mrisr_norm_blend": (_i, [_i, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_upsample2_stats": (_i, [_i, _vp, _vp, _dp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_upsample2_adjoint": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_act_bwd_reduce": (_i, [_i, _vp, _fp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),

@@ -545,6 +545,50 @@ extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// out = sigmoid(alpha) * act0 + (1 - sigmoid(alpha)) * act1, act_i = LeakyReLU(x_i*scale_i+shift_i)  (unet_model.py:206-207):
+// the blended input of final_conv.0, materialised.  With 32 channels the conv and its weight gradient are
+// staging-bound, and the two-source blending loader doubles that staging; one plain tensor halves it.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_blend_kernel(const T* __restrict__ x0, const float* __restrict__ sc0,
+                                                         const float* __restrict__ sh0, const T* __restrict__ x1,
+                                                         const float* __restrict__ sc1, const float* __restrict__ sh1,
+                                                         const float* __restrict__ alpha, T* __restrict__ out, int N,
+                                                         size_t HW, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nvec = C / VEC;
+    const size_t total = (size_t)N * HW * nvec;
+    const float a = 1.f / (1.f + __expf(-alpha[0])), b = 1.f - a;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cv = idx % nvec;
+        const size_t pix = idx / nvec;
+        const int n = pix / HW;
+        const size_t k0 = (size_t)n * C + cv * VEC;
+        const Vec16<T> v0 = load_vec16(x0 + idx * VEC), v1 = load_vec16(x1 + idx * VEC);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            o.set(e, a * lrelu(v0.get(e) * sc0[k0 + e] + sh0[k0 + e]) + b * lrelu(v1.get(e) * sc1[k0 + e] + sh1[k0 + e]));
+        store_vec16(out + idx * VEC, o);
+    }
+}
+
+extern "C" int mrisr_norm_blend(int dtype, const void* x0, const float* scale0, const float* shift0, const void* x1,
+                                const float* scale1, const float* shift1, const float* alpha, void* out, int N, int H,
+                                int W, int C, void* stream) {
+    if (!x0 || !scale0 || !shift0 || !x1 || !scale1 || !shift1 || !alpha || !out) MRISR_FAIL(MRISR_E_ARG, "norm_blend: null pointer");
+    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    if (N <= 0 || H <= 0 || W <= 0 || C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_blend: N %d H %d W %d C %d", N, H, W, C);
+    const size_t total = (size_t)N * H * W * (C / vec);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) norm_blend_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x0, scale0, shift0, (const bf16_t*)x1, scale1, shift1, alpha, (bf16_t*)out, N, (size_t)H * W, C);
+    else if (dtype == MRISR_F32) norm_blend_kernel<float><<<blocks, 256, 0, s>>>((const float*)x0, scale0, shift0, (const float*)x1, scale1, shift1, alpha, (float*)out, N, (size_t)H * W, C);
+    else MRISR_FAIL(MRISR_E_DTYPE, "norm_blend: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("norm_blend");
+    return MRISR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // dalpha += sigmoid'(alpha) * sum da * (act0 - act1)        (unet_model.py:206-207)
 template <typename T>
 __global__ __launch_bounds__(256) void blend_alpha_grad_kernel(const T* __restrict__ da, const T* __restrict__ x0,

@@ -69,6 +69,7 @@ class Layer:
     out_mode: int = L.OUT_PLAIN
     pool_src: bool = False      # source = materialised MaxPool2d(2) of the activated source node (encoder)
     up_src: bool = False        # source = materialised bilinear x2 of the activated source node (final_up_bilinear)
+    blend_src: bool = False     # source = materialised alpha blend of the two activated source nodes (final_conv.0)
     post_up: bool = False       # 1x1 conv evaluated at low resolution, bilinear x2 applied to its output
     # per-forward geometry / saved tensors
     H: int = 0
@@ -157,8 +158,10 @@ class UNetEngine:
         self.layers.append(Layer("final_up_pixelshuffle.conv", f, 2 * f, 3, [Source(u)], ps, bias=True,
                                  out_mode=L.OUT_PIXEL_SHUFFLE2))
         fc = node("final_conv.0", f // 2, "final_conv.1.weight", "final_conv.1.bias")
+        # the blended input is materialised (measured: the 32-channel conv and its weight gradient are staging-bound,
+        # and the two-source blending loader doubles the staging work)
         self.layers.append(Layer("final_conv.0", f // 2, f // 2, 3, [Source(fb), Source(ps)], fc,
-                                 combine=L.COMBINE_BLEND))
+                                 combine=L.COMBINE_BLEND, blend_src=True))
         self.head_in = fc
         self._packed: Dict[tuple, torch.Tensor] = {}
         self._pack_versions: Dict[tuple, int] = {}
@@ -231,6 +234,12 @@ class UNetEngine:
         d.dtype, d.N, d.H, d.W = dt, N, layer.H, layer.W
         d.Cin, d.Cout, d.ksize, d.nsrc = layer.cin, layer.cout, layer.ks, len(layer.srcs)
         d.combine, d.out_mode, d.groups, d.relu_out = layer.combine, layer.out_mode, GN_GROUPS, 0
+        if layer.blend_src:                         # materialised blend: one plain source
+            d.nsrc, d.combine = 1, L.COMBINE_CONCAT
+            d.src[0].ptr = layer.aux.data_ptr()
+            d.src[0].C, d.src[0].H, d.src[0].W = layer.cin, layer.H, layer.W
+            d.src[0].mode, d.src[0].spatial = L.SRC_RAW, L.SP_NONE
+            return d
         for i, (s, (oy, ox)) in enumerate(zip(layer.srcs, layer.offs)):
             n = s.node
             if layer.pool_src or layer.up_src:      # materialised pooled / upsampled activation: a plain tensor
@@ -308,6 +317,14 @@ class UNetEngine:
                 layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
                 L.call("mrisr_norm_upsample2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
                        layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st)
+            if layer.blend_src:
+                a, b = layer.srcs[0].node, layer.srcs[1].node
+                if (a.H, a.W, a.C) != (b.H, b.W, b.C):
+                    raise RuntimeError(f"{layer.name}: blend sources differ in shape")
+                layer.aux = torch.empty((N, a.H, a.W, a.C), dtype=dtype, device=dev)
+                L.call("mrisr_norm_blend", dt, a.raw.data_ptr(), a.scale.data_ptr(), a.shift.data_ptr(), b.raw.data_ptr(),
+                       b.scale.data_ptr(), b.shift.data_ptr(), params["alpha"].data_ptr(), layer.aux.data_ptr(),
+                       N, a.H, a.W, a.C, st)
             layer.H, layer.W = vh, vw
             layer.offs = []
             for sidx, src in enumerate(layer.srcs):
