@@ -172,7 +172,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         }
     };
     // issue the global loads of a work item (geometry in `geom`, image n, cin chunk kc)
-    auto issue = [&](int n, int kc) {
+    // streamed weights (not weights-stationary): the next chunk's image, issued at the start of the matrix phase
+    // (L2-resident, and keeping these 36 VGPRs dead during the epilogue avoids spills)
+    auto issue_weights = [&](int kc) {
         if (p.dbg & 4) return;
         if constexpr (!WS) {
             const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase + (size_t)kc * (WIMG_VECS * 16));
@@ -182,6 +184,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 if (v < WIMG_VECS) pf.w[j].v = gload<decltype(pf.w[j].v)>(wsrc + v);
             }
         }
+    };
+    auto issue = [&](int n, int kc) {
+        if (p.dbg & 4) return;
         if constexpr (pf_halo) {
             const int c0 = kc * (kRowBytes / (int)sizeof(T)) + (t & 3) * VEC;
             int which = 0, cs = c0;
@@ -329,6 +334,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     auto epilogue = [&](int n, int ty0, int tx0) {
         if (p.dbg & 16) return;
         T* outp = (T*)p.out;
+        int lh_e = lh;      // opaque copy: channel-dependent store addresses are recomputed per tile, not hoisted (and spilled)
+        asm volatile("" : "+v"(lh_e));
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int pl = wave * 64 + mi * 32 + lr;
@@ -340,10 +347,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             for (int ni = 0; ni < NF; ++ni) {
                 if (has_br) {   // block-uniform: bias (from LDS) and ReLU applied in place on the accumulators
                     const float floor_v = p.relu_out ? 0.f : -INFINITY;
+                    const float* bl = lds_bias + 4 * lh_e;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         // (channels >= Cout: zero weights and a zero LDS bias keep them at exactly 0)
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds_bias + ni * 32 + 8 * q + 4 * lh);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ni * 32 + 8 * q);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[ni][mi][4 * q + j] = fmaxf(acc[ni][mi][4 * q + j] + b[j], floor_v);
                     }
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 u32x2 packed[4];          // bf16 plain epilogue: the 4 quads of this fragment, packed
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int co = bn0 + ni * 32 + 8 * q + 4 * lh;      // first of 4 consecutive couts
+                    const int co = bn0 + ni * 32 + 8 * q + 4 * lh_e;      // first of 4 consecutive couts
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                         auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                         u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        const int co8 = bn0 + ni * 32 + 8 * (q + lh);      // first of the 8 channels this lane now owns
+                        const int co8 = bn0 + ni * 32 + 8 * (q + lh_e);      // first of the 8 channels this lane now owns
                         if (pv && co8 < p.Cout && !(p.dbg & 1)) {
                             if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
                                 const u32x4 m = gload<u32x4>((const T*)p.mask + pix * p.Cout + co8);
@@ -410,11 +418,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 }
                 if constexpr (EPI == MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
                     // PixelShuffle(2): conv channel 4c'+2i+j -> pixel (2y+i, 2x+j), channel c'.  packed[q] = the four
-                    // (i,j) values of c' = cb + 2q + lh.  For one (i,j): this lane holds c' = cb + {0,2,4,6} + lh; one
+                    // (i,j) values of c' = cb + 2q + lh_e.  For one (i,j): this lane holds c' = cb + {0,2,4,6} + lh_e; one
                     // permlane32 swap + a 16-bit interleave give the low half c' = cb..cb+3 and the high half
                     // cb+4..cb+7 -> one 8-byte store per (i,j) instead of four 2-byte stores.
                     const int C4 = p.Cout >> 2, cb = (bn0 + ni * 32) >> 2;
-                    const bool okc = cb + 4 * lh < C4;                 // (C4 % 4 == 0: host-checked for this epilogue)
+                    const bool okc = cb + 4 * lh_e < C4;                 // (C4 % 4 == 0: host-checked for this epilogue)
 #pragma unroll
                     for (int ij = 0; ij < 4; ++ij) {
                         // 16-bit element ij of packed[q]: dword ij>>1, half ij&1
@@ -422,12 +430,12 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                             const unsigned a = packed[qa][ij >> 1], b = packed[qb][ij >> 1];
                             return (ij & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
                         };
-                        const unsigned P0 = pick(0, 1), P1 = pick(2, 3);          // own c' = {0,2}+lh and {4,6}+lh
+                        const unsigned P0 = pick(0, 1), P1 = pick(2, 3);          // own c' = {0,2}+lh_e and {4,6}+lh_e
                         auto r = __builtin_amdgcn_permlane32_swap(P0, P1, false, false);   // P0.hi-lanes <-> P1.lo-lanes
                         const unsigned X = r[0], Y = r[1];   // low half: X={0,2} Y={1,3}; high half: X={4,6} Y={5,7}
                         const u32x2 o = {(X & 0xffffu) | (Y << 16), (X >> 16) | (Y & 0xffff0000u)};
                         if (pv && okc && !(p.dbg & 1))
-                            gstore(outp + ((size_t)(n * 2 * p.H + 2 * oy + (ij >> 1)) * (2 * p.W) + 2 * ox + (ij & 1)) * C4 + cb + 4 * lh, o);
+                            gstore(outp + ((size_t)(n * 2 * p.H + 2 * oy + (ij >> 1)) * (2 * p.W) + 2 * ox + (ij & 1)) * C4 + cb + 4 * lh_e, o);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // bound the scheduling window: one (mi, ni) group's temporaries live at a time
@@ -442,6 +450,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     if (nitems > 0) {
         decode(cur_tile, cur_n, cur_ty0, cur_tx0);
         set_geom(cur_n, cur_ty0, cur_tx0);
+        issue_weights(0);
         issue(cur_n, 0);
     }
     for (int tick = 0; tick < nticks; ++tick) {
@@ -449,11 +458,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         const int c = phase >> 1;
         if (phase >= 0 && (phase & 1) == 0) {
             // ------------------------------------------------ vector phase
-            if (ep_pending) {
-                epilogue(ep_n, ep_ty0, ep_tx0);
-                if (p.stats && (c >= nitems || cur_n != ep_n)) flush_stats(ep_n);
-                ep_pending = false;
-            }
+            // Order: commit item c (its loads were issued one full tick pair ago) -> issue the loads of item c+1
+            // right away (the prefetch registers are free again) -> only then the epilogue of the tile that finished
+            // in the previous matrix phase.  The loads thus have the rest of this phase plus the whole matrix phase
+            // to land; issued at the start of the matrix phase they had half of that and the commit stalled on
+            // vmcnt (measured: 20-40 us per launch).
             if (c < nitems) {
                 commit(cur_n, cur_kc, cur_ty0, cur_tx0);
                 nxt_tile = cur_tile; nxt_kc = cur_kc + 1; nxt_n = cur_n; nxt_ty0 = cur_ty0; nxt_tx0 = cur_tx0;
@@ -465,10 +474,16 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         set_geom(nxt_n, nxt_ty0, nxt_tx0);
                     }
                 }
+                issue(nxt_n, nxt_kc);     // unconditional: after the last item this re-loads valid addresses and is never committed
+            }
+            if (ep_pending) {
+                epilogue(ep_n, ep_ty0, ep_tx0);
+                if (p.stats && (c >= nitems || cur_n != ep_n)) flush_stats(ep_n);
+                ep_pending = false;
             }
         } else if (phase >= 0 && c < nitems) {
             // ------------------------------------------------ matrix phase
-            if (c + 1 < nitems) issue(nxt_n, nxt_kc);
+            issue_weights(nxt_kc);    // unconditional (a redundant load after the last item): keeps the registers dead between commit and here
             const char* wl = lds_w + (WS ? (size_t)cur_kc * (WIMG_VECS * 16) : 0);
             // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
             // out of the persistent loop into 36 VGPRs

@@ -230,10 +230,12 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
 
     // Schedule.  The two waves that share a SIMD (tap groups 0 and 1) run the iteration in opposite orders, so that
     // one is in its MFMA block while the other does the VALU/LDS-store work of staging the next tile:
-    //   tap group 0:  issue loads(tile k+1) -> MFMA(tile k) -> commit(tile k+1)
-    //   tap group 1:  commit(tile k+1, loads issued one iteration earlier) -> issue loads(tile k+2) -> MFMA(tile k)
-    // Each thread stages its own slots of the double-buffered LDS image; the barrier at the end of iteration k
-    // separates the writes of buffer (k+1)&1 from its reads in iteration k+1 and from its last reads in k-1.
+    //   tap group 0:  MFMA(tile k) -> commit(tile k+1) -> issue loads(tile k+2)
+    //   tap group 1:  commit(tile k+1) -> issue loads(tile k+2) -> MFMA(tile k)
+    // Either way the operands of tile k+1 were requested a full iteration earlier (the commit does not stall on
+    // vmcnt) and sit in registers during MFMA(k).  Each thread stages its own slots of the double-buffered LDS image;
+    // the barrier at the end of iteration k separates the writes of buffer (k+1)&1 from its reads in iteration k+1
+    // and from its last reads in k-1.
     int tile = blockIdx.y, n = 0, ty0 = 0, tx0 = 0, cur = 0;
     int pn = 0, pty0 = 0, ptx0 = 0;                           // group 1: tile whose operands are in registers
     if (tile < total_tiles) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         set_geom(n, ty0, tx0);
         issue(n, ty0, tx0);
         commit(smem, n);
-        if (tgu == 1 && tile + (int)gridDim.y < total_tiles) {
+        if (tile + (int)gridDim.y < total_tiles) {
             decode(tile + gridDim.y, pn, pty0, ptx0);
             set_geom(pn, pty0, ptx0);
             issue(pn, pty0, ptx0);
@@ -304,12 +306,12 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto mfma_block = [&]() {
+    auto mfma_block = [&](auto tg_tag) {      // tg_tag: the (wave-uniform) tap group of the calling site
         const char* lds_dy = smem + cur * buf_bytes;
         const char* lds_in = lds_dy + 256 * 128;
         if (p.dbg & 8) {
         } else if constexpr (FAST) {
-            if (tgu == 0) mfma_fast(std::integral_constant<int, 0>{});
+            if constexpr (decltype(tg_tag)::value == 0) mfma_fast(std::integral_constant<int, 0>{});
             else mfma_fast(std::integral_constant<int, 1>{});
         } else if constexpr (kBf16) {
             // generic path (small images / channel blocks narrower than 64): keep its per-lane address pieces from
@@ -363,15 +365,15 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     while (tile < total_tiles) {
         const int nxt = tile + gridDim.y;
         const bool has_next = nxt < total_tiles;
-        if (tgu == 1 && has_next) commit(smem + (cur ^ 1) * buf_bytes, pn);       // loads issued one iteration ago
-        const int it = tgu ? nxt + (int)gridDim.y : nxt;                            // tile to start loading now
+        if (tgu == 0) mfma_block(std::integral_constant<int, 0>{});
+        if (has_next) commit(smem + (cur ^ 1) * buf_bytes, pn);      // operands loaded during the previous iteration
+        const int it = nxt + (int)gridDim.y;                          // start loading the tile after next
         if (it < total_tiles) {
             decode(it, pn, pty0, ptx0);
             set_geom(pn, pty0, ptx0);
-            issue(pn, pty0, ptx0);                  // global loads fly while the MFMAs below run
+            issue(pn, pty0, ptx0);                  // a full iteration (~2 us) for the loads to land
         }
-        mfma_block();
-        if (tgu == 0 && has_next) commit(smem + (cur ^ 1) * buf_bytes, pn);
+        if (tgu == 1) mfma_block(std::integral_constant<int, 1>{});
         __syncthreads();
         cur ^= 1;
         tile = nxt;
