@@ -260,22 +260,22 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C;
     int rc = fill_act_bwd_params(p, dtype, nconsumers, consumers, blend_alpha, H, W, C, "act_bwd_apply_fused");
     if (rc) return rc;
-    const size_t total = (size_t)N * H * W * (C / vec);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
     hipStream_t s = (hipStream_t)stream;
     bool same = true;
     for (int k = 0; k < nconsumers; ++k)
         same = same && consumers[k].H == H && consumers[k].W == W && consumers[k].off_y == 0 && consumers[k].off_x == 0;
-    const int nvec = C / vec;
-    p.nvec_shift = -1;
-    for (int sft = 0; sft < 16; ++sft)
-        if ((1 << sft) == nvec) p.nvec_shift = sft;
+    const int nvec = C / vec, ppb = 256 / nvec, HW = H * W;
+    int ppblk = ppb * 32;
+    if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
+    p.pix_per_block = ppblk;
+    dim3 grid(ceil_div(HW, ppblk), N);
     if (dtype == MRISR_BF16) {
-        if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<blocks, 256, 0, s>>>(p, coef, (bf16_t*)dx);
-        else act_bwd_apply_fused_kernel<bf16_t, false><<<blocks, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+        if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+        else act_bwd_apply_fused_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
     } else if (dtype == MRISR_F32) {
-        if (same) act_bwd_apply_fused_kernel<float, true><<<blocks, 256, 0, s>>>(p, coef, (float*)dx);
-        else act_bwd_apply_fused_kernel<float, false><<<blocks, 256, 0, s>>>(p, coef, (float*)dx);
+        if (same) act_bwd_apply_fused_kernel<float, true><<<grid, 256, 0, s>>>(p, coef, (float*)dx);
+        else act_bwd_apply_fused_kernel<float, false><<<grid, 256, 0, s>>>(p, coef, (float*)dx);
     } else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
     return MRISR_OK;
@@ -303,7 +303,7 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
         p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode};
     }
     const int nvec = C / vec, ppb = 256 / nvec;
-    int ppblk = ppb * 16;
+    int ppblk = ppb * 16;      // (32 measured slower: fewer blocks, longer tail)
     const int HW = H * W;
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     p.pix_per_block = ppblk;
@@ -413,45 +413,52 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const T* __restrict_
 // LeakyReLU' applied, then dx = g*cA + x*cB + cC.  Saves the 2-byte write of pass 1 and reads da instead of g.
 // SAME: every consumer gradient has the node's own H x W and no pad offset (all but the odd-size decoder nodes): the
 // consumer element is addressed by the linear pixel index - no div/mod per element.
+// Block = (pixel range, image), thread = (pixel lane, 16-byte channel vector): the five per-(n,c) coefficient vectors
+// are loaded ONCE per thread.  Re-loading them per element put 160 B of L1 traffic next to every 48 B of HBM traffic
+// and capped the pass at ~3.7 TB/s.
 template <typename T, bool SAME>
 __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef,
                                                                   T* __restrict__ dx) {
     constexpr int VEC = Vec16<T>::N;
-    const int nvec = p.C / VEC;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = p.C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    if (pl >= ppb) return;
     const size_t NC = (size_t)p.N * p.C;
-    const size_t HW = (size_t)p.H * p.W;
-    const size_t total = (size_t)p.N * HW * nvec;
-    float bw[3] = {1.f, 1.f, 1.f};
+    const int HW = p.H * p.W;
+    float bw1 = 1.f, bw2 = 1.f;
     if (p.blend_alpha) {
-        const float a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
-        bw[1] = a;
-        bw[2] = 1.f - a;
+        bw1 = 1.f / (1.f + __expf(-p.blend_alpha[0]));
+        bw2 = 1.f - bw1;
     }
     const int m0 = p.cons[0].weight_mode, m1 = p.cons[1].weight_mode;
-    const float w0 = m0 == 0 ? 1.f : (m0 == 1 ? bw[1] : bw[2]), w1 = m1 == 0 ? 1.f : (m1 == 1 ? bw[1] : bw[2]);
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int cv;
-        size_t gpix;
-        if (p.nvec_shift >= 0) { cv = (int)(idx & (nvec - 1)); gpix = idx >> p.nvec_shift; }
-        else { cv = idx % nvec; gpix = idx / nvec; }
-        const int c = cv * VEC;
-        const Vec16<T> xv = load_vec16((const T*)p.x + gpix * p.C + c);
+    const float w0 = m0 == 0 ? 1.f : (m0 == 1 ? bw1 : bw2), w1 = m1 == 0 ? 1.f : (m1 == 1 ? bw1 : bw2);
+    float sc[VEC], sh[VEC], ca[VEC], cb[VEC], cc[VEC];
+    const size_t k0 = (size_t)n * p.C + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = p.scale[k0 + e]; sh[e] = p.shift[k0 + e];
+        ca[e] = coef[k0 + e]; cb[e] = coef[NC + k0 + e]; cc[e] = coef[2 * NC + k0 + e];
+    }
+    const T* xb = (const T*)p.x + (size_t)n * HW * p.C + c;
+    T* ob = dx + (size_t)n * HW * p.C + c;
+    const T* d0b = (const T*)p.cons[0].da + (size_t)n * p.cons[0].H * p.cons[0].W * p.cons[0].C_total + p.cons[0].c_off + c;
+    const T* d1b = p.ncons > 1 ? (const T*)p.cons[1].da + (size_t)n * p.cons[1].H * p.cons[1].W * p.cons[1].C_total + p.cons[1].c_off + c : d0b;
+    const int pend = min(HW, (int)(blockIdx.x + 1) * p.pix_per_block);
+    for (int pix = blockIdx.x * p.pix_per_block + pl; pix < pend; pix += ppb) {
+        const Vec16<T> xv = load_vec16(xb + (size_t)pix * p.C);
         float gact[VEC];
-        int n;
         if constexpr (SAME) {
-            const Vec16<T> d0 = load_vec16((const T*)p.cons[0].da + gpix * p.cons[0].C_total + p.cons[0].c_off + c);
+            const Vec16<T> d0 = load_vec16(d0b + (size_t)pix * p.cons[0].C_total);
             if (p.ncons > 1) {
-                const Vec16<T> d1 = load_vec16((const T*)p.cons[1].da + gpix * p.cons[1].C_total + p.cons[1].c_off + c);
+                const Vec16<T> d1 = load_vec16(d1b + (size_t)pix * p.cons[1].C_total);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) gact[e] = w0 * d0.get(e) + w1 * d1.get(e);
             } else {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) gact[e] = w0 * d0.get(e);
             }
-            n = (int)(gpix / HW);
         } else {
-            n = (int)(gpix / HW);
-            const int pix = (int)(gpix - (size_t)n * HW);
             const int y = pix / p.W, x = pix - y * p.W;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) gact[e] = 0.f;
@@ -459,29 +466,22 @@ __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdPa
                 const ConsumerDev& cs = p.cons[k];
                 const int yy = y + cs.off_y, xx = x + cs.off_x;
                 if (yy < cs.H && xx < cs.W) {
-                    const Vec16<T> d = load_vec16((const T*)cs.da + (((size_t)n * cs.H + yy) * cs.W + xx) * cs.C_total + cs.c_off + c);
-                    const float wgt = cs.weight_mode == 0 ? 1.f : (cs.weight_mode == 1 ? bw[1] : bw[2]);
+                    const Vec16<T> d = load_vec16((k ? d1b : d0b) + ((size_t)yy * cs.W + xx) * cs.C_total);
+                    const float wgt = k ? w1 : w0;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
                 }
             }
         }
         Vec16<T> o;
-        const size_t k0 = (size_t)n * p.C + c;          // multiple of VEC: 16-byte aligned float4 loads
 #pragma unroll
-        for (int e4 = 0; e4 < VEC; e4 += 4) {
-            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + k0 + e4), sh4 = *reinterpret_cast<const f32x4*>(p.shift + k0 + e4);
-            const f32x4 ca = *reinterpret_cast<const f32x4*>(coef + k0 + e4), cb = *reinterpret_cast<const f32x4*>(coef + NC + k0 + e4),
-                        cc = *reinterpret_cast<const f32x4*>(coef + 2 * NC + k0 + e4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xr = xv.get(e4 + j);
-                const float pre = xr * sc4[j] + sh4[j];
-                const float gy = gact[e4 + j] * (pre > 0.f ? 1.f : LRELU_SLOPE);
-                o.set(e4 + j, gy * ca[j] + xr * cb[j] + cc[j]);
-            }
+        for (int e = 0; e < VEC; ++e) {
+            const float xr = xv.get(e);
+            const float pre = xr * sc[e] + sh[e];
+            const float gy = gact[e] * (pre > 0.f ? 1.f : LRELU_SLOPE);
+            o.set(e, gy * ca[e] + xr * cb[e] + cc[e]);
         }
-        store_vec16(dx + gpix * p.C + c, o);
+        store_vec16(ob + (size_t)pix * p.C, o);
     }
 }
 
@@ -910,25 +910,24 @@ extern "C" int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, 
 template <typename T>
 __global__ __launch_bounds__(256) void norm_upsample2_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, T* __restrict__ out, int N,
-                                                             int h, int w, int C) {
+                                                             int h, int w, int C, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    const int nvec = C / VEC, H = 2 * h, W = 2 * w;
-    const size_t total = (size_t)N * H * W * nvec;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int cv = idx % nvec;
-        size_t r = idx / nvec;
-        const int X = r % W; r /= W;
-        const int Y = r % H;
-        const int n = r / H;
-        const int c = cv * VEC;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = C / VEC, ppb = 256 / nvec, H = 2 * h, W = 2 * w, HW = H * W;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    if (pl >= ppb) return;
+    float sc[VEC], sh[VEC];            // hoisted: one (n, channel vector) per thread
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
+    const T* b = x + (size_t)n * h * w * C + c;
+    T* ob = out + (size_t)n * HW * C + c;
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+        const int Y = pix / W, X = pix - Y * W;
         int y0, y1, x0, x1;
         float wy, wx;
         up2_coord(Y, h, y0, y1, wy);
         up2_coord(X, w, x0, x1, wx);
-        float sc[VEC], sh[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
-        const T* b = x + (size_t)n * h * w * C + c;
         const Vec16<T> v00 = load_vec16(b + ((size_t)y0 * w + x0) * C), v01 = load_vec16(b + ((size_t)y0 * w + x1) * C);
         const Vec16<T> v10 = load_vec16(b + ((size_t)y1 * w + x0) * C), v11 = load_vec16(b + ((size_t)y1 * w + x1) * C);
         Vec16<T> o;
@@ -938,7 +937,7 @@ __global__ __launch_bounds__(256) void norm_upsample2_kernel(const T* __restrict
             const float cq = lrelu(v10.get(e) * sc[e] + sh[e]), d = lrelu(v11.get(e) * sc[e] + sh[e]);
             o.set(e, (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * cq + wx * d));
         }
-        store_vec16(out + idx * VEC, o);
+        store_vec16(ob + (size_t)pix * C, o);
     }
 }
 
@@ -947,10 +946,13 @@ extern "C" int mrisr_norm_upsample2(int dtype, const void* x, const float* scale
     if (!x || !scale || !shift || !out) MRISR_FAIL(MRISR_E_ARG, "norm_upsample2: null pointer");
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d", C);
-    const size_t total = (size_t)N * 4 * h * w * (C / vec);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (dtype == MRISR_BF16) norm_upsample2_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, h, w, C);
-    else if (dtype == MRISR_F32) norm_upsample2_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, h, w, C);
+    if (C / vec > 256 || N <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d N %d", C, N);
+    const int nvec = C / vec, ppb = 256 / nvec, HW = 4 * h * w;
+    int ppblk = ppb * 32;
+    if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
+    dim3 grid(ceil_div(HW, ppblk), N);
+    if (dtype == MRISR_BF16) norm_upsample2_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, h, w, C, ppblk);
+    else if (dtype == MRISR_F32) norm_upsample2_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, h, w, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "norm_upsample2: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("norm_upsample2");
     return MRISR_OK;
