@@ -118,13 +118,6 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
         sA[e] = 0.f;
         sB[e] = 0.f;
     }
-    float mean[VEC], rstd[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const int g = (c + e) / gs;
-        mean[e] = p.meanrstd[((size_t)n * p.groups + g) * 2];
-        rstd[e] = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
-    }
     float bw[3] = {1.f, 1.f, 1.f};
     if (p.blend_alpha) {
         const float a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
@@ -206,10 +199,18 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
                 gv.set(e, gy);
                 const float gq = p.g ? gv.get(e) : gy;      // the value pass 2 will use (rounded when it goes through g)
                 sA[e] += gq;
-                sB[e] += gq * ((xr - mean[e]) * rstd[e]);
+                sB[e] += gq * xr;                           // sum g*x; turned into sum g*xhat after the loop
             }
             if (p.g) store_vec16(gb + (size_t)pix * p.C + c, gv);
         }
+    }
+    // sum g*xhat = rstd * (sum g*x - mean * sum g), per thread (<= 16 pixels each: no cancellation to speak of); the
+    // group statistics are only needed here, so they stay out of the streaming loop's register budget
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (c + e) / gs;
+        const float mean = p.meanrstd[((size_t)n * p.groups + g) * 2], rstd = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
+        sB[e] = rstd * (sB[e] - mean * sA[e]);
     }
     // block reduction over the pixel lanes that share a channel vector
 #pragma unroll
