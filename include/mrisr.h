@@ -166,12 +166,17 @@ typedef struct {
  *  finalize: dgamma[C] += sum_n red[..][1], dbeta[C] += sum_n red[..][0], coef[3][N][C] such that
  *            dx = g*coef0 + x*coef1 + coef2      (count = (C/groups)*H*W)
  *  apply   : writes dx (dtype); out_mode PIXEL_SHUFFLE2 stores it un-shuffled as [N][H/2][W/2][4C].  */
+/* alpha_slots (optional, 256 zeroed floats; first consumer plain, blend_alpha set): receives partial sums of
+ * (first consumer's unweighted gradient) * activation; mrisr_act_bwd_finalize turns them into
+ * dalpha += alpha_sign * sigmoid'(alpha) * sum  (+1 for the sigmoid(alpha) branch, -1 for the other; the two branches'
+ * terms add up to unet_model.py:206-207's dL/dalpha, so mrisr_blend_alpha_grad's extra pass is not needed).      */
 int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift,
                          const float* meanrstd, int nconsumers, const mrisr_consumer* consumers,
-                         const float* blend_alpha, void* g, float* red, int N, int H, int W, int C,
-                         int groups, void* stream);
+                         const float* blend_alpha, void* g, float* red, float* alpha_slots, int N, int H, int W,
+                         int C, int groups, void* stream);
 int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* meanrstd, float* dgamma,
-                           float* dbeta, float* coef, int N, int C, int groups, double count, void* stream);
+                           float* dbeta, float* coef, int N, int C, int groups, double count,
+                           const float* alpha_slots, const float* alpha, float* dalpha, float alpha_sign, void* stream);
 int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N,
                         int H, int W, int C, int out_mode, void* stream);
 /* apply without the intermediate tensor: when every consumer is MRISR_SP_NONE, mrisr_act_bwd_reduce may be called

@@ -65,6 +65,7 @@ struct ActBwdParams {
     ConsumerDev cons[2];
     int ncons, N, H, W, C, groups, pix_per_block;
     int nvec_shift;  // log2(C / VEC) when that is a power of two, else -1
+    float* alpha_slots;   // [256] partial sums of (first consumer's gradient) * activation, or NULL (blend alpha gradient)
 };
 
 template <typename T>
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
     const T* xb = (const T*)p.x + (size_t)n * HW * p.C;
     T* gb = (T*)p.g + (size_t)n * HW * p.C;
     const int pix_end = min(HW, (int)(blockIdx.x + 1) * p.pix_per_block);
+    float adot = 0.f;
     if (active) {
         for (int pix = blockIdx.x * p.pix_per_block + pl; pix < pix_end; pix += ppb) {
             const int y = pix / p.W, x = pix - y * p.W;
@@ -144,6 +146,10 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
                         const Vec16<T> d = load_vec16(dab + ((size_t)yy * cs.W + xx) * cs.C_total);
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) gact[e] += wgt * d.get(e);
+                        if (p.alpha_slots && k == 0) {       // blend branch: sum d * act feeds dL/dalpha
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) adot += d.get(e) * lrelu(xv.get(e) * sc[e] + sh[e]);
+                        }
                     }
                 } else if constexpr (PLAIN) {
                 } else if (cs.spatial == MRISR_SP_POOL2) {
@@ -211,6 +217,10 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
         const int g = (c + e) / gs;
         const float mean = p.meanrstd[((size_t)n * p.groups + g) * 2], rstd = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
         sB[e] = rstd * (sB[e] - mean * sA[e]);
+    }
+    if (p.alpha_slots) {      // one atomic per wave, spread over 256 slots (summed by act_bwd_finalize)
+        const float w = wave_sum(active ? adot : 0.f);
+        if ((t & 63) == 0) atomic_add_f32(&p.alpha_slots[(blockIdx.x * 4 + (t >> 6) + blockIdx.y * 37) & 255], w);
     }
     // block reduction over the pixel lanes that share a channel vector
 #pragma unroll
@@ -284,8 +294,8 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
 
 extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift,
                                     const float* meanrstd, int nconsumers, const mrisr_consumer* consumers,
-                                    const float* blend_alpha, void* g, float* red, int N, int H, int W, int C,
-                                    int groups, void* stream) {
+                                    const float* blend_alpha, void* g, float* red, float* alpha_slots, int N, int H,
+                                    int W, int C, int groups, void* stream) {
     if (!x || !scale || !shift || !meanrstd || !red || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: null pointer");
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: %d consumers", nconsumers);
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
@@ -293,6 +303,8 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     ActBwdParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.scale = scale; p.shift = shift; p.meanrstd = meanrstd; p.blend_alpha = blend_alpha; p.g = g; p.red = red;
+    p.alpha_slots = alpha_slots;
+    if (alpha_slots && (consumers[0].spatial != MRISR_SP_NONE || !blend_alpha)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: alpha_slots needs a plain first consumer and blend_alpha");
     p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C; p.groups = groups;
     for (int k = 0; k < nconsumers; ++k) {
         const mrisr_consumer& c = consumers[k];
@@ -335,7 +347,17 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
 __global__ void act_bwd_finalize_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
                                         const float* __restrict__ meanrstd, float* __restrict__ dgamma,
                                         float* __restrict__ dbeta, float* __restrict__ coef, int N, int C,
-                                        int groups, float inv_count) {
+                                        int groups, float inv_count, const float* __restrict__ alpha_slots,
+                                        const float* __restrict__ alpha, float* __restrict__ dalpha, float alpha_sign) {
+    if (alpha_slots && blockIdx.x == 0) {   // dalpha += sign * sigmoid'(alpha) * sum d*act  (unet_model.py:206-207)
+        float v = 0.f;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) v += alpha_slots[i];
+        v = wave_sum(v);
+        if (threadIdx.x == 0) {
+            const float sg = 1.f / (1.f + __expf(-alpha[0]));
+            atomic_add_f32(dalpha, alpha_sign * sg * (1.f - sg) * v);
+        }
+    }
     // one block per (n, group); coef is [3][N][C]
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int gs = C / groups;
@@ -368,11 +390,14 @@ __global__ void act_bwd_finalize_kernel(const float* __restrict__ red, const flo
 
 extern "C" int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* meanrstd, float* dgamma,
                                       float* dbeta, float* coef, int N, int C, int groups, double count,
+                                      const float* alpha_slots, const float* alpha, float* dalpha, float alpha_sign,
                                       void* stream) {
     if (!red || !gamma || !meanrstd || !dgamma || !dbeta || !coef) MRISR_FAIL(MRISR_E_ARG, "act_bwd_finalize: null pointer");
     if (groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_finalize: C %d groups %d", C, groups);
+    if (alpha_slots && (!alpha || !dalpha)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_finalize: alpha_slots without alpha/dalpha");
     act_bwd_finalize_kernel<<<N * groups, 64, 0, (hipStream_t)stream>>>(red, gamma, meanrstd, dgamma, dbeta, coef, N, C,
-                                                                       groups, (float)(1.0 / count));
+                                                                       groups, (float)(1.0 / count), alpha_slots, alpha,
+                                                                       dalpha, alpha_sign);
     MRISR_CHECK_LAUNCH("act_bwd_finalize");
     return MRISR_OK;
 }

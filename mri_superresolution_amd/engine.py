@@ -391,7 +391,8 @@ class UNetEngine:
         dout = dout.contiguous()
 
         # one zero-filled arena for the per-node (sum g, sum g*xhat) buffers instead of 20 small fills
-        red_sizes = [N * n.C * 2 for n in self.nodes.values()]
+        # (+256 floats per node: slots of the blend-alpha partial sums, used by the two head branches only)
+        red_sizes = [N * n.C * 2 + 256 for n in self.nodes.values()]
         red_arena = torch.zeros(sum(red_sizes), dtype=torch.float32, device=dev)
         red_off = {}
         o = 0
@@ -414,13 +415,19 @@ class UNetEngine:
             g = None if fused else torch.empty_like(n.raw)
             alpha_ptr = params["alpha"].data_ptr() if uses_alpha else None
             red = red_arena[red_off[n.name][0]:red_off[n.name][0] + red_off[n.name][1]]
+            # blend branches: dL/dalpha = sigmoid'(alpha) * sum dain * (act_bilinear - act_pixelshuffle) falls out of
+            # the two branches' reduce passes (sum dain*act each), no extra pass over the three tensors
+            wm0 = n.consumers[0][8]
+            slots = red[N * n.C * 2:] if (wm0 != 0 and n.consumers[0][5] == L.SP_NONE) else None
             L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
-                   n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(),
+                   n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(), L.ptr(slots),
                    N, n.H, n.W, n.C, GN_GROUPS, st)
             coef = torch.empty(3 * N * n.C, dtype=torch.float32, device=dev)
             count = float((n.C // GN_GROUPS) * n.H * n.W)
             L.call("mrisr_act_bwd_finalize", red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
-                   grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), coef.data_ptr(), N, n.C, GN_GROUPS, count, st)
+                   grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), coef.data_ptr(), N, n.C, GN_GROUPS, count,
+                   L.ptr(slots), alpha_ptr, grads["alpha"].data_ptr() if slots is not None else None,
+                   1.0 if wm0 == 1 else -1.0, st)
             if fused:
                 dx = torch.empty_like(n.raw)
                 L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
@@ -476,9 +483,6 @@ class UNetEngine:
             self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))
             if layer.combine == L.COMBINE_BLEND:
                 a, b = layer.srcs[0].node, layer.srcs[1].node
-                L.call("mrisr_blend_alpha_grad", dt, dain.data_ptr(), a.raw.data_ptr(), a.scale.data_ptr(),
-                       a.shift.data_ptr(), b.raw.data_ptr(), b.scale.data_ptr(), b.shift.data_ptr(),
-                       params["alpha"].data_ptr(), grads["alpha"].data_ptr(), N, layer.H, layer.W, layer.cin, st)
                 a.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 1))
                 b.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 2))
             elif layer.up_src:

@@ -253,11 +253,11 @@ def test_act_backward(dt, mode):
     g = torch.empty_like(xd)
     red = torch.zeros(n * c * 2, device=U.DEV)
     L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), len(cons), carr,
-           None, g.data_ptr(), red.data_ptr(), n, h, w, c, 8, U.stream())
+           None, g.data_ptr(), red.data_ptr(), None, n, h, w, c, 8, U.stream())
     dgam, dbet, coef = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.empty(3 * n * c, device=U.DEV)
     gdev = gamma.to(U.DEV)
     L.call("mrisr_act_bwd_finalize", red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
-           coef.data_ptr(), n, c, 8, float((c // 8) * h * w), U.stream())
+           coef.data_ptr(), n, c, 8, float((c // 8) * h * w), None, None, None, 0.0, U.stream())
     if mode == "shuffled":
         dx = torch.empty((n, h // 2, w // 2, 4 * c), dtype=U.tdt(dt), device=U.DEV)
         L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PIXEL_SHUFFLE2, U.stream())
@@ -287,6 +287,23 @@ def test_blend_alpha_grad_and_channel_sum(dt):
     dev = [U.nhwc(da, dt), U.nhwc(x0, dt), s0.to(U.DEV), t0.to(U.DEV), U.nhwc(x1, dt), s1.to(U.DEV), t1.to(U.DEV), alpha.detach().reshape(1).to(U.DEV)]
     L.call("mrisr_blend_alpha_grad", dt, *[t.data_ptr() for t in dev], dal.data_ptr(), n, h, w, c, U.stream())
     assert abs(dal.item() - alpha.grad.item()) <= 1e-4 * abs(alpha.grad.item()) + 1e-5
+    # the same gradient as a by-product of the two branches' backward reduce passes (alpha_slots)
+    dal2 = torch.zeros(1, device=U.DEV)
+    for xi, si, ti, wm, sign in ((dev[1], dev[2], dev[3], 1, 1.0), (dev[4], dev[5], dev[6], 2, -1.0)):
+        carr = (L.Consumer * 2)()
+        carr[0].da, carr[0].C_total, carr[0].c_off, carr[0].H, carr[0].W = dev[0].data_ptr(), c, 0, h, w
+        carr[0].spatial, carr[0].weight_mode = L.SP_NONE, wm
+        red = torch.zeros(n * c * 2 + 256, device=U.DEV)
+        mr = torch.zeros(n * 8 * 2, device=U.DEV)
+        mr[1::2] = 1.0
+        L.call("mrisr_act_bwd_reduce", dt, xi.data_ptr(), si.data_ptr(), ti.data_ptr(), mr.data_ptr(), 1, carr,
+               dev[7].data_ptr(), None, red.data_ptr(), red[n * c * 2:].data_ptr(), n, h, w, c, 8, U.stream())
+        dg, db, coef = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.empty(3 * n * c, device=U.DEV)
+        gam = torch.ones(c, device=U.DEV)
+        L.call("mrisr_act_bwd_finalize", red.data_ptr(), gam.data_ptr(), mr.data_ptr(), dg.data_ptr(), db.data_ptr(),
+               coef.data_ptr(), n, c, 8, float((c // 8) * h * w), red[n * c * 2:].data_ptr(), dev[7].data_ptr(),
+               dal2.data_ptr(), sign, U.stream())
+    assert abs(dal2.item() - alpha.grad.item()) <= 2e-4 * abs(alpha.grad.item()) + 1e-5
     cs = torch.zeros(c, device=U.DEV)
     L.call("mrisr_channel_sum", dt, dev[0].data_ptr(), cs.data_ptr(), n * h * w, c, U.stream())
     assert U.relerr(cs.cpu(), U.rounded(da, dt).sum((0, 2, 3))) <= 1e-4
