@@ -165,7 +165,8 @@ typedef struct {
  *            and accumulates red[N][C][2] += (sum g, sum g*xhat) (fp32)
  *  finalize: dgamma[C] += sum_n red[..][1], dbeta[C] += sum_n red[..][0], coef[3][N][C] such that
  *            dx = g*coef0 + x*coef1 + coef2      (count = (C/groups)*H*W)
- *  apply   : writes dx (dtype); out_mode PIXEL_SHUFFLE2 stores it un-shuffled as [N][H/2][W/2][4C].  */
+ *  apply   : writes dx (dtype); out_mode PIXEL_SHUFFLE2 stores it un-shuffled as [N][H/2][W/2][4C]; dbias (optional,
+ *            that mode only, [4C] fp32 accumulated) += per-channel sums of dx = the producing conv's bias gradient. */
 /* alpha_slots (optional, 256 zeroed floats; first consumer plain, blend_alpha set): receives partial sums of
  * (first consumer's unweighted gradient) * activation; mrisr_act_bwd_finalize turns them into
  * dalpha += alpha_sign * sigmoid'(alpha) * sum  (+1 for the sigmoid(alpha) branch, -1 for the other; the two branches'
@@ -178,7 +179,7 @@ int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* me
                            float* dbeta, float* coef, int N, int C, int groups, double count,
                            const float* alpha_slots, const float* alpha, float* dalpha, float alpha_sign, void* stream);
 int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N,
-                        int H, int W, int C, int out_mode, void* stream);
+                        int H, int W, int C, int out_mode, float* dbias, void* stream);
 /* apply without the intermediate tensor: when every consumer is MRISR_SP_NONE, mrisr_act_bwd_reduce may be called
  * with g = NULL and this entry gathers dL/dact from the consumers again (same arguments as the reduce pass).    */
 int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift, int nconsumers,

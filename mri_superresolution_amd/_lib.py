@@ -63,7 +63,7 @@ SIGNATURES = {
     "mrisr_upsample2_adjoint": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_act_bwd_reduce": (_i, [_i, _vp, _fp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_act_bwd_finalize": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _fp, _fp, _fp, _f, _vp]),
-    "mrisr_act_bwd_apply": (_i, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_act_bwd_apply": (_i, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _fp, _vp]),
     "mrisr_act_bwd_apply_fused": (_i, [_i, _vp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_channel_sum": (_i, [_i, _vp, _fp, _sz, _i, _vp]),
     "mrisr_blend_alpha_grad": (_i, [_i, _vp, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -517,8 +517,12 @@ __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdPa
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_apply_unshuffle_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                                       const float* __restrict__ coef, T* __restrict__ dx,
-                                                                      int N, int H, int W, int C) {
+                                                                      int N, int H, int W, int C, float* __restrict__ dbias) {
     constexpr int VEC = Vec16<T>::N, NSC = VEC / 4;      // source channels per thread
+    __shared__ float bsum[256 * VEC];
+    float bs[VEC];                                       // per-thread channel sums of dx (= the conv's bias gradient)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bs[e] = 0.f;
     const int H2 = H / 2, W2 = W / 2, ndv = 4 * C / VEC;
     const size_t NC = (size_t)N * C;
     const size_t total = (size_t)N * H2 * W2 * ndv;
@@ -541,22 +545,41 @@ __global__ __launch_bounds__(256) void act_bwd_apply_unshuffle_kernel(const T* _
             }
         }
         store_vec16(dx + idx * VEC, o);
+        if (dbias) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) bs[e] += o.get(e);     // (the rounded value the weight-gradient kernel will read)
+        }
+    }
+    if (dbias) {
+        // the grid stride is a multiple of ndv (host-checked), so a thread keeps its destination vector dv = t % ndv
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bsum[t * VEC + e] = bs[e];
+        __syncthreads();
+        for (int i = t; i < ndv * VEC; i += 256) {
+            const int dv = i / VEC, e = i - dv * VEC;
+            float v = 0.f;
+            for (int q = dv; q < 256; q += ndv) v += bsum[q * VEC + e];
+            atomic_add_f32(&dbias[dv * VEC + e], v);
+        }
     }
 }
 
 extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N, int H,
-                                   int W, int C, int out_mode, void* stream) {
+                                   int W, int C, int out_mode, float* dbias, void* stream) {
     if (!x || !g || !coef || !dx) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply: null pointer");
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: C %d", C);
     if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && ((H | W) & 1)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: odd dims with pixel shuffle");
     const size_t total = (size_t)N * H * W * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dbias && !(out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (4 * C) % vec == 0 && 256 % (4 * C / vec) == 0))
+        MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply: dbias needs the pixel-shuffle output with 4C/vec dividing 256");
     if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (4 * C) % vec == 0) {
         if (dtype == MRISR_BF16)
-            act_bwd_apply_unshuffle_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C);
+            act_bwd_apply_unshuffle_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C, dbias);
         else if (dtype == MRISR_F32)
-            act_bwd_apply_unshuffle_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)g, coef, (float*)dx, N, H, W, C);
+            act_bwd_apply_unshuffle_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)g, coef, (float*)dx, N, H, W, C, dbias);
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply: dtype %d", dtype);
         MRISR_CHECK_LAUNCH("act_bwd_apply");
         return MRISR_OK;

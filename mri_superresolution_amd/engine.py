@@ -400,7 +400,7 @@ class UNetEngine:
             red_off[n.name] = (o, sz)
             o += sz
 
-        def node_backward(n: Node) -> torch.Tensor:
+        def node_backward(n: Node, dbias=None) -> torch.Tensor:
             """dL/dact (gathered from consumers) -> dL/d(raw conv output), plus GN affine grads."""
             cons = (L.Consumer * 2)()
             uses_alpha = False
@@ -441,7 +441,7 @@ class UNetEngine:
                 dx = torch.empty_like(n.raw)
                 mode = L.OUT_PLAIN
             L.call("mrisr_act_bwd_apply", dt, n.raw.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(),
-                   N, n.H, n.W, n.C, mode, st)
+                   N, n.H, n.W, n.C, mode, L.ptr(dbias) if n.shuffled else None, st)
             n.consumers = []
             return dx
 
@@ -458,7 +458,9 @@ class UNetEngine:
 
         for layer in reversed(self.layers):
             o = layer.out
-            dy = node_backward(o)
+            # pixel-shuffle conv with bias: its bias gradient (channel sums of dy) comes out of the un-shuffling pass
+            fuse_bias = layer.bias and o.shuffled
+            dy = node_backward(o, grads[layer.name + ".bias"] if fuse_bias else None)
             if layer.post_up:       # adjoint of the bilinear x2 that follows the low-resolution 1x1 conv
                 dyl = torch.empty((N, layer.H, layer.W, layer.cout), dtype=dtype, device=dev)
                 L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st)
@@ -466,7 +468,7 @@ class UNetEngine:
             d = self._desc(layer, dt, N, params)
             self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
                                                     grads[layer.name + ".weight"].data_ptr(), st))
-            if layer.bias:
+            if layer.bias and not fuse_bias:
                 L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
                        N * layer.H * layer.W, layer.cout, st)
             # input gradient: the same implicit-GEMM kernel on dy with mirrored, transposed weights

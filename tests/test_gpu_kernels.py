@@ -260,11 +260,13 @@ def test_act_backward(dt, mode):
            coef.data_ptr(), n, c, 8, float((c // 8) * h * w), None, None, None, 0.0, U.stream())
     if mode == "shuffled":
         dx = torch.empty((n, h // 2, w // 2, 4 * c), dtype=U.tdt(dt), device=U.DEV)
-        L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PIXEL_SHUFFLE2, U.stream())
+        dbias = torch.zeros(4 * c, device=U.DEV)
+        L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PIXEL_SHUFFLE2, dbias.data_ptr(), U.stream())
         got = F.pixel_shuffle(U.nchw(dx), 2)
+        assert U.relerr(dbias.cpu(), U.nchw(dx).sum((0, 2, 3))) <= (1e-4 if dt == L.F32 else 2e-3)
     else:
         dx = torch.empty_like(xd)
-        L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PLAIN, U.stream())
+        L.call("mrisr_act_bwd_apply", dt, xd.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(), n, h, w, c, L.OUT_PLAIN, None, U.stream())
         got = U.nchw(dx)
     torch.cuda.synchronize()
     tol = 3e-4 if dt == L.F32 else 2e-2
