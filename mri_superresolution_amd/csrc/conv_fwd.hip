@@ -109,6 +109,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         for (int v = threadIdx.x; v < p.nchunks * WIMG_VECS; v += kFwdThreads) reinterpret_cast<u32x4*>(lds_w)[v] = gload<u32x4>(wsrc + v);
     }
     const bool has_br = p.bias != nullptr || p.relu_out != 0;      // block-uniform: epilogue with bias / ReLU
+    const bool all_raw = p.src[0].mode == MRISR_SRC_RAW && (p.nsrc < 2 || p.src[1].mode == MRISR_SRC_RAW);   // block-uniform
     if (threadIdx.x < BN) lds_bias[threadIdx.x] = (p.bias && bn0 + (int)threadIdx.x < p.Cout) ? gload<float>(p.bias + bn0 + threadIdx.x) : 0.f;
 
     // per-lane LDS byte offsets of its two pixels' halo rows (tap (0,0), k-step 0) and of its weight row
@@ -255,18 +256,29 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
         }
         if constexpr (NH == 1) {
-            // straight-line: y = x*sc+sh, act = max(y, slope*y), masked slots -> 0, unpredicated 16-B LDS store
+            if (all_raw) {
+                // every source is stored as-is (input gradients, materialised activations, VGG): no arithmetic at all,
+                // the loaded vectors go to LDS with the padding slots zeroed
 #pragma unroll
-            for (int i = 0; i < kMaxHaloIter; ++i) {
-                Vec16<T> v = pf.h[i][0];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float y = fmaf(v.get(e), pf.sc[e], pf.sh[e]);
-                    v.set(e, fmaxf(y, pf.slope * y));
+                for (int i = 0; i < kMaxHaloIter; ++i) {
+                    Vec16<T> v = pf.h[i][0];
+                    if (!((pf.mask >> i) & 1)) v.zero();
+                    *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
                 }
-                if (!((pf.mask >> i) & 1)) v.zero();
-                *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots' temporaries live at a time
+            } else {
+                // straight-line: y = x*sc+sh, act = max(y, slope*y), masked slots -> 0, unpredicated 16-B LDS store
+#pragma unroll
+                for (int i = 0; i < kMaxHaloIter; ++i) {
+                    Vec16<T> v = pf.h[i][0];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float y = fmaf(v.get(e), pf.sc[e], pf.sh[e]);
+                        v.set(e, fmaxf(y, pf.slope * y));
+                    }
+                    if (!((pf.mask >> i) & 1)) v.zero();
+                    *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots' temporaries live at a time
+                }
             }
         } else if constexpr (pf_halo) {
 #pragma unroll
