@@ -92,7 +92,9 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MRISR_FORCE_DP=1 (rehearsal on a one-GPU box): run the RCCL data-parallel path with a single rank
+    force_dp = os.environ.get("MRISR_FORCE_DP") == "1" and "RANK" in os.environ
+    if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -118,7 +120,7 @@ def main():
         vgg_eng = fe._engine
     metric = SSIM(device=dev)
     dp = None
-    if world > 1:
+    if world > 1 or force_dp:
         dp = DataParallel(model)
         opt.grad_scale = 1.0 / world
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -148,7 +150,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -161,7 +163,7 @@ def main():
         last = step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dp:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -183,7 +185,7 @@ def main():
         model._engine.timer = None
         if vgg_eng is not None:
             vgg_eng.timer = None
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
 
     if rank == 0:
@@ -227,7 +229,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args.base_filters, S, args.ssim_weight)
         rec["loss"] = float(last.detach()) if not args.forward_only else None
         print(json.dumps(rec))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 
