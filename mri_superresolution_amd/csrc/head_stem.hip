@@ -4,43 +4,61 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ stem
+// Input rows of the block's pixel range (+1 row above and below) staged in LDS: the 9 taps of a pixel are LDS reads
+// shared by the Cout/VEC threads of that pixel; as 9 predicated 4-byte global loads per thread the pass was bound by
+// load-instruction issue (1.7 TB/s).  rows_lds = rows staged, first image row r0 (may be -1: zero row).
+template <typename T>
+__device__ __forceinline__ void stem_stage_rows(const float* __restrict__ xb, float* rows, int H, int W, int r0, int nrows, int t) {
+    for (int i = t; i < nrows * W; i += 256) {
+        const int r = r0 + i / W;
+        rows[i] = (r >= 0 && r < H) ? xb[(size_t)r * W + (i - (i / W) * W)] : 0.f;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        T* __restrict__ out, double* __restrict__ stats, int H, int W,
-                                                       int Cout, int groups, int pix_per_block) {
+                                                       int Cout, int groups, int pix_per_block, int max_rows) {
     constexpr int VEC = Vec16<T>::N;
     extern __shared__ double smd[];          // [groups*2] statistics (fp64: the order of the LDS atomics must not
     double* sst = smd;                       //  perturb mean / rstd - a 1e-7 wobble flips LeakyReLU signs run to run)
-    float* sw = reinterpret_cast<float*>(smd + 2 * (groups > 0 ? groups : 1));     // then [Cout*9] weights
+    float* rows = reinterpret_cast<float*>(smd + 2 * (groups > 0 ? groups : 1));     // then [max_rows][W] input rows
     const int t = threadIdx.x, n = blockIdx.y;
-    for (int i = t; i < Cout * 9; i += 256) sw[i] = w[i];
+    const int HW = H * W;
+    const int p0 = blockIdx.x * pix_per_block, pend = min(HW, p0 + pix_per_block);
+    const int r0 = p0 / W - 1, nrows = (pend - 1) / W + 1 - r0 + 1;
+    const float* xb = x + (size_t)n * HW;
+    stem_stage_rows<T>(xb, rows, H, W, r0, nrows, t);
     for (int i = t; i < groups * 2; i += 256) sst[i] = 0.0;
-    __syncthreads();
     const int nvec = Cout / VEC, ppb = 256 / nvec;
     const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
-    const int HW = H * W, gs = groups > 0 ? Cout / groups : Cout;
-    const float* xb = x + (size_t)n * HW;
+    const int gs = groups > 0 ? Cout / groups : Cout;
+    float wr[VEC][9];                        // this thread's 8 output channels x 9 taps, in registers
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[e][k] = w[(c + e) * 9 + k];
+    __syncthreads();
     float s[VEC], ss[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
     if (pl < ppb)
-        for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+        for (int pix = p0 + pl; pix < pend; pix += ppb) {
             const int y = pix / W, xx = pix - y * W;
+            const float* rl = rows + (y - 1 - r0) * W + xx;     // row y-1 of the staged rows, column xx
             float in[9];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int yy = y + r - 1, xq = xx + q - 1;
-                    in[r * 3 + q] = (yy >= 0 && yy < H && xq >= 0 && xq < W) ? xb[yy * W + xq] : 0.f;
-                }
+            for (int r = 0; r < 3; ++r) {
+                in[r * 3 + 0] = xx > 0 ? rl[r * W - 1] : 0.f;
+                in[r * 3 + 1] = rl[r * W];
+                in[r * 3 + 2] = xx + 1 < W ? rl[r * W + 1] : 0.f;
+            }
             Vec16<T> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float a = 0.f;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) a += in[k] * sw[(c + e) * 9 + k];
+                for (int k = 0; k < 9; ++k) a += in[k] * wr[e][k];
                 o.set(e, a);
                 const float q = o.get(e);
                 s[e] += q;
@@ -62,17 +80,27 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
+static int stem_block_pixels(int W, int ppb, int& max_rows) {
+    // pixels per block: ~8 image rows (at least ppb*8 pixels), so the staged rows (+2) stay a small multiple of W
+    int ppblk = ppb * 64;
+    if (ppblk < 4 * W) ppblk = ceil_div(4 * W, ppb) * ppb;
+    max_rows = ppblk / W + 4;
+    return ppblk;
+}
+
 extern "C" int mrisr_stem_forward(int dtype, const float* x, const float* w, void* out, double* stats, int N, int H,
                                   int W, int Cout, int groups, void* stream) {
     if (!x || !w || !out) MRISR_FAIL(MRISR_E_ARG, "stem_forward: null pointer");
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (Cout % vec || Cout / vec > 256 || (stats && (groups <= 0 || Cout % groups))) MRISR_FAIL(MRISR_E_SHAPE, "stem_forward: Cout %d", Cout);
     const int ppb = 256 / (Cout / vec);
-    int ppblk = ppb * 64;
+    int max_rows;
+    const int ppblk = stem_block_pixels(W, ppb, max_rows);
     dim3 grid(ceil_div(H * W, ppblk), N);
-    const size_t lds = (size_t)Cout * 9 * sizeof(float) + (size_t)(groups > 0 ? groups : 1) * 2 * sizeof(double);
-    if (dtype == MRISR_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, H, W, Cout, groups, ppblk);
-    else if (dtype == MRISR_F32) stem_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (float*)out, stats, H, W, Cout, groups, ppblk);
+    const size_t lds = (size_t)max_rows * W * sizeof(float) + (size_t)(groups > 0 ? groups : 1) * 2 * sizeof(double);
+    if (lds > 64 * 1024) MRISR_FAIL(MRISR_E_UNSUPPORTED, "stem_forward: image width %d too large for the row cache", W);
+    if (dtype == MRISR_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, H, W, Cout, groups, ppblk, max_rows);
+    else if (dtype == MRISR_F32) stem_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (float*)out, stats, H, W, Cout, groups, ppblk, max_rows);
     else MRISR_FAIL(MRISR_E_DTYPE, "stem_forward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("stem_forward");
     return MRISR_OK;
@@ -84,11 +112,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                                                          float* __restrict__ dw, int H, int W, int Cout, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float lds[256 * 9];
+    extern __shared__ float rows[];          // [max_rows][W] input rows of this block's pixel range (see stem_fwd_kernel)
     const int t = threadIdx.x, n = blockIdx.y;
     const int nvec = Cout / VEC, ppb = 256 / nvec;
     const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
     const int HW = H * W;
     const float* xb = x + (size_t)n * HW;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int r0 = p0 / W - 1, nrows = (min(HW, p0 + pix_per_block) - 1) / W + 1 - r0 + 1;
+    stem_stage_rows<T>(xb, rows, H, W, r0, nrows, t);
+    __syncthreads();
     float acc[VEC][9];
 #pragma unroll
     for (int e = 0; e < VEC; ++e)
@@ -98,14 +131,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     if (pl < ppb)
         for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
             const int y = pix / W, xx = pix - y * W;
+            const float* rl = rows + (y - 1 - r0) * W + xx;
             float in[9];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int yy = y + r - 1, xq = xx + q - 1;
-                    in[r * 3 + q] = (yy >= 0 && yy < H && xq >= 0 && xq < W) ? xb[yy * W + xq] : 0.f;
-                }
+            for (int r = 0; r < 3; ++r) {
+                in[r * 3 + 0] = xx > 0 ? rl[r * W - 1] : 0.f;
+                in[r * 3 + 1] = rl[r * W];
+                in[r * 3 + 2] = xx + 1 < W ? rl[r * W + 1] : 0.f;
+            }
             const Vec16<T> d = load_vec16(dy + ((size_t)n * HW + pix) * Cout + c);
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
@@ -134,10 +167,13 @@ extern "C" int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (Cout % vec || Cout / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "stem_wgrad: Cout %d", Cout);
     const int ppb = 256 / (Cout / vec);
-    const int ppblk = ppb * 64;
+    int max_rows;
+    const int ppblk = stem_block_pixels(W, ppb, max_rows);
     dim3 grid(ceil_div(H * W, ppblk), N);
-    if (dtype == MRISR_BF16) stem_wgrad_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dy, dw, H, W, Cout, ppblk);
-    else if (dtype == MRISR_F32) stem_wgrad_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(x, (const float*)dy, dw, H, W, Cout, ppblk);
+    const size_t lds = (size_t)max_rows * W * sizeof(float);
+    if (lds > 48 * 1024) MRISR_FAIL(MRISR_E_UNSUPPORTED, "stem_wgrad: image width %d too large for the row cache", W);
+    if (dtype == MRISR_BF16) stem_wgrad_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, (const bf16_t*)dy, dw, H, W, Cout, ppblk);
+    else if (dtype == MRISR_F32) stem_wgrad_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, (const float*)dy, dw, H, W, Cout, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "stem_wgrad: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("stem_wgrad");
     return MRISR_OK;
