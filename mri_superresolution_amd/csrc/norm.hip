@@ -238,6 +238,117 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
     }
 }
 
+// Nodes whose activation is also max-pooled (the encoder skips x1..x3): thread = (pooled pixel, channel vector) owning
+// the whole 2x2 window - the four activations and the arg-max are computed ONCE per window (the per-pixel kernel
+// recomputed them in each of the window's four threads and needed 120-140 VGPRs), for pass 1 (APPLY = false:
+// per-(n,c) sums) and pass 2 (APPLY = true: dx, no intermediate g tensor).  Needs even H, W and - if there is a
+// second consumer - a plain one with the node's own geometry (host-checked: act_bwd_window_ok).
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void act_bwd_pool_window_kernel(const ActBwdParams p, const float* __restrict__ coef,
+                                                                  T* __restrict__ dx) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float lds[APPLY ? 2 : 256 * VEC * 2];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = p.C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    const bool active = pl < ppb;
+    const int Hp = p.H / 2, Wp = p.W / 2, HWp = Hp * Wp, W = p.W;
+    const int kp = p.cons[0].spatial == MRISR_SP_POOL2 ? 0 : 1, ko = 1 - kp;
+    const bool has_o = p.ncons > 1;
+    float bw1 = 1.f, bw2 = 1.f;
+    if (p.blend_alpha) { bw1 = 1.f / (1.f + __expf(-p.blend_alpha[0])); bw2 = 1.f - bw1; }
+    const int mp = p.cons[kp].weight_mode, mo = has_o ? p.cons[ko].weight_mode : 0;
+    const float wp = mp == 0 ? 1.f : (mp == 1 ? bw1 : bw2), wo = mo == 0 ? 1.f : (mo == 1 ? bw1 : bw2);
+    const size_t k0 = (size_t)n * p.C + c, NC = (size_t)p.N * p.C;
+    float sc[VEC], sh[VEC], u0[VEC], u1[VEC], u2[VEC];     // APPLY: u = (cA, cB, cC); reduce: u0 = sum g, u1 = sum g*x
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = p.scale[k0 + e]; sh[e] = p.shift[k0 + e];
+        if constexpr (APPLY) { u0[e] = coef[k0 + e]; u1[e] = coef[NC + k0 + e]; u2[e] = coef[2 * NC + k0 + e]; }
+        else { u0[e] = 0.f; u1[e] = 0.f; u2[e] = 0.f; }
+    }
+    const T* xb = (const T*)p.x + (size_t)n * p.H * W * p.C + c;
+    const T* dpb = (const T*)p.cons[kp].da + (size_t)n * HWp * p.cons[kp].C_total + p.cons[kp].c_off + c;
+    const int Cto = has_o ? p.cons[ko].C_total : 0;
+    const T* dob = has_o ? (const T*)p.cons[ko].da + (size_t)n * p.H * W * Cto + p.cons[ko].c_off + c : xb;
+    T* ob = APPLY ? dx + (size_t)n * p.H * W * p.C + c : nullptr;
+    const int pend = min(HWp, (int)(blockIdx.x + 1) * p.pix_per_block);
+    if (active) {
+        for (int pp = blockIdx.x * p.pix_per_block + pl; pp < pend; pp += ppb) {
+            const int py = pp / Wp, px = pp - py * Wp;
+            const size_t b0 = (size_t)(2 * py) * W + 2 * px;
+            const size_t off[4] = {b0, b0 + 1, b0 + W, b0 + W + 1};
+            Vec16<T> xv[4], dv[4], ov[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = load_vec16(xb + off[q] * p.C);
+            const Vec16<T> dp = load_vec16(dpb + (size_t)pp * p.cons[kp].C_total);
+            if (has_o) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dv[q] = load_vec16(dob + off[q] * Cto);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float xr[4], pre[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { xr[q] = xv[q].get(e); pre[q] = xr[q] * sc[e] + sh[e]; }
+                // first maximum of the activations in scan order (aten max_pool2d); LeakyReLU is monotone, so the
+                // comparison runs on act = lrelu(pre)
+                int win = 0;
+                float m = lrelu(pre[0]);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float a = lrelu(pre[q]);
+                    if (a > m) { m = a; win = q; }
+                }
+                const float gp = wp * dp.get(e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float gact = q == win ? gp : 0.f;
+                    if (has_o) gact += wo * dv[q].get(e);
+                    const float gy = gact * (pre[q] > 0.f ? 1.f : LRELU_SLOPE);
+                    if constexpr (APPLY) ov[q].set(e, gy * u0[e] + xr[q] * u1[e] + u2[e]);
+                    else { u0[e] += gy; u1[e] += gy * xr[q]; }
+                }
+            }
+            if constexpr (APPLY) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) store_vec16(ob + off[q] * p.C, ov[q]);
+            }
+        }
+    }
+    if constexpr (!APPLY) {
+        const int gs = p.C / p.groups;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int g = (c + e) / gs;
+            const float mean = p.meanrstd[((size_t)n * p.groups + g) * 2], rstd = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
+            u1[e] = rstd * (u1[e] - mean * u0[e]);
+            lds[(t * VEC + e) * 2] = active ? u0[e] : 0.f;
+            lds[(t * VEC + e) * 2 + 1] = active ? u1[e] : 0.f;
+        }
+        __syncthreads();
+        for (int i = t; i < nvec * VEC * 2; i += 256) {
+            const int j = i >> 1, which = i & 1;
+            const int cvj = j / VEC, e = j - cvj * VEC;
+            float s = 0.f;
+            for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
+            atomic_add_f32(&p.red[((size_t)n * p.C + cvj * VEC + e) * 2 + which], s);
+        }
+    }
+}
+
+// window kernels apply when: one 2x2-pool consumer, even H and W, and the optional second consumer is plain with the
+// node's own geometry
+static bool act_bwd_window_ok(int nconsumers, const mrisr_consumer* cs, int H, int W) {
+    if ((H | W) & 1) return false;
+    int npool = 0;
+    for (int k = 0; k < nconsumers; ++k) {
+        if (cs[k].spatial == MRISR_SP_POOL2) ++npool;
+        else if (cs[k].spatial != MRISR_SP_NONE || cs[k].H != H || cs[k].W != W || cs[k].off_y || cs[k].off_x) return false;
+    }
+    return npool == 1;
+}
+
 template <typename T, bool SAME>
 __global__ void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef, T* __restrict__ dx);
 
@@ -263,8 +374,10 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: %d consumers", nconsumers);
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
-    for (int k = 0; k < nconsumers; ++k)
-        if (consumers[k].spatial != MRISR_SP_NONE) MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply_fused: plain consumers only");
+    bool plain = true;
+    for (int k = 0; k < nconsumers; ++k) plain = plain && consumers[k].spatial == MRISR_SP_NONE;
+    const bool window = !plain && act_bwd_window_ok(nconsumers, consumers, H, W);
+    if (!plain && !window) MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply_fused: plain consumers (or one 2x2-pool consumer on an even-sized node) only");
     ActBwdParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.scale = scale; p.shift = shift; p.blend_alpha = blend_alpha;
@@ -273,6 +386,18 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     if (rc) return rc;
     if (C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
     hipStream_t s = (hipStream_t)stream;
+    if (window) {
+        const int nvw = C / vec, ppbw = 256 / nvw, HWp = (H / 2) * (W / 2);
+        int ppw = ppbw * 16;
+        if (ppw > HWp) ppw = ceil_div(HWp, ppbw) * ppbw;
+        p.pix_per_block = ppw;
+        dim3 gridw(ceil_div(HWp, ppw), N);
+        if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, true><<<gridw, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+        else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, true><<<gridw, 256, 0, s>>>(p, coef, (float*)dx);
+        else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
+        MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
+        return MRISR_OK;
+    }
     bool same = true;
     for (int k = 0; k < nconsumers; ++k)
         same = same && consumers[k].H == H && consumers[k].W == W && consumers[k].off_y == 0 && consumers[k].off_x == 0;
@@ -321,6 +446,23 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     p.pix_per_block = ppblk;
     dim3 grid(ceil_div(HW, ppblk), N);
+    if (!g && !alpha_slots && act_bwd_window_ok(nconsumers, consumers, H, W)) {     // pass 1 of the window pair
+        const int HWp = (H / 2) * (W / 2);
+        int ppw = ppb * 16;
+        if (ppw > HWp) ppw = ceil_div(HWp, ppb) * ppb;
+        p.pix_per_block = ppw;
+        dim3 gridw(ceil_div(HWp, ppw), N);
+        hipStream_t sw = (hipStream_t)stream;
+        if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (bf16_t*)nullptr);
+        else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, false><<<gridw, 256, 0, sw>>>(p, nullptr, (float*)nullptr);
+        else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
+        MRISR_CHECK_LAUNCH("act_bwd_reduce");
+        return MRISR_OK;
+    }
+    if (!g) {
+        for (int k = 0; k < nconsumers; ++k)
+            if (consumers[k].spatial != MRISR_SP_NONE) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: g = NULL needs plain consumers or a window-eligible pooled node");
+    }
     int kind = 0;
     for (int k = 0; k < nconsumers; ++k) {
         if (consumers[k].spatial == MRISR_SP_POOL2 && kind < 1) kind = 1;

@@ -411,7 +411,13 @@ class UNetEngine:
                 uses_alpha |= wm != 0
             # plain consumers (no pool gather) and a plain output: pass 2 re-gathers dL/dact instead of going through
             # a materialised g tensor (one 2-byte write + read per element less)
-            fused = (not n.shuffled) and all(c[5] == L.SP_NONE for c in n.consumers)
+            # (a 2x2-pooled node on even dims qualifies too: the window kernels own a whole pooling window per thread)
+            plain = all(c[5] == L.SP_NONE for c in n.consumers)
+            window = (not plain and n.H % 2 == 0 and n.W % 2 == 0
+                      and sum(c[5] == L.SP_POOL2 for c in n.consumers) == 1
+                      and all(c[5] == L.SP_POOL2 or (c[5] == L.SP_NONE and (c[3], c[4], c[6], c[7]) == (n.H, n.W, 0, 0))
+                              for c in n.consumers))
+            fused = (not n.shuffled) and (plain or window)
             g = None if fused else torch.empty_like(n.raw)
             alpha_ptr = params["alpha"].data_ptr() if uses_alpha else None
             red = red_arena[red_off[n.name][0]:red_off[n.name][0] + red_off[n.name][1]]
