@@ -718,6 +718,9 @@ extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, cons
     if (dbias && !(out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (4 * C) % vec == 0 && 256 % (4 * C / vec) == 0))
         MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply: dbias needs the pixel-shuffle output with 4C/vec dividing 256");
     if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (4 * C) % vec == 0) {
+        // with the bias gradient every block ends in 4C same-address atomics: 8192 blocks made that tail as long as
+        // the pass itself (measured 298 vs 144 us) -> fewer, longer-running blocks
+        const int blocks = dbias ? (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024) : (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         if (dtype == MRISR_BF16)
             act_bwd_apply_unshuffle_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C, dbias);
         else if (dtype == MRISR_F32)
