@@ -111,7 +111,12 @@ int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream);
 int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out, size_t n);
 /* weight gradient: dw[Cout][k][k][Cin] (fp32, ACCUMULATED) = sum_pix dy[pix][co] * in[pix+tap][ci];
  * the input is described exactly as in the forward desc (d->out, d->wpacked, d->bias ignored). */
-int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, void* stream);
+int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, float* workspace, size_t workspace_floats,
+                     void* stream);
+/* workspace (optional, caller-owned scratch of >= mrisr_conv_wgrad_workspace_floats(d) floats): the split-K partial
+ * sums go through it and a second kernel adds them into dw; with NULL (or a smaller buffer) they are added with
+ * float atomics directly (same result up to summation order, slower).                                            */
+size_t mrisr_conv_wgrad_workspace_floats(const mrisr_conv_desc* d);
 
 /* stem conv Cin==1 (unet_model.py:29 for "inc"): x fp32 [N][H][W], w fp32 [Cout][9]          */
 int mrisr_stem_forward(int dtype, const float* x, const float* w, void* out, double* stats,

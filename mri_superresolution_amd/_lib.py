@@ -52,7 +52,8 @@ SIGNATURES = {
     "mrisr_pack_weights_batched": (_i, [_i, _vp, _i, _vp]),
     "mrisr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "mrisr_conv_variant": (_i, [C.POINTER(ConvDesc), _i, C.c_char_p, _sz]),
-    "mrisr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _fp, _vp]),
+    "mrisr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _fp, _fp, _sz, _vp]),
+    "mrisr_conv_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc)]),
     "mrisr_stem_forward": (_i, [_i, _fp, _fp, _vp, _dp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_stem_wgrad": (_i, [_i, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),
     "mrisr_gn_finalize": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _f, _vp]),

@@ -55,6 +55,7 @@ struct ConvParams {
     const void* mask; // forward: relu_mask (epilogue kEpiMask), same layout as out
     const void* dy;   // wgrad only
     float* dw;        // wgrad only
+    float* wsp;       // wgrad only: partial-sum workspace (two-stage reduction) or NULL (atomics into dw)
     int N, H, W, Cin, CinP, Cout, CoutP;
     int nsrc, combine, out_mode, groups, relu_out;
     int tw_log2, th, tiles_x, tiles_y, ncb, nchunks;
@@ -72,7 +73,7 @@ __device__ __forceinline__ ConvParams pin_params(const ConvParams& in) {
     PIN_F(q, in, H) PIN_F(q, in, W) PIN_F(q, in, Cout) PIN_F(q, in, N) PIN_F(q, in, nchunks) PIN_F(q, in, tw_log2)
     PIN_F(q, in, th) PIN_F(q, in, tiles_x) PIN_F(q, in, tiles_y) PIN_F(q, in, nsrc) PIN_F(q, in, dbg)
     PIN_F(q, in, groups) PIN_F(q, in, relu_out) PIN_F(q, in, out) PIN_F(q, in, stats) PIN_F(q, in, bias)
-    PIN_F(q, in, dy) PIN_F(q, in, dw) PIN_F(q, in, mask) PIN_F(q, in, Cin) PIN_F(q, in, combine)
+    PIN_F(q, in, dy) PIN_F(q, in, dw) PIN_F(q, in, wsp) PIN_F(q, in, mask) PIN_F(q, in, Cin) PIN_F(q, in, combine)
     PIN_F(q, in, src[0].ptr) PIN_F(q, in, src[0].scale) PIN_F(q, in, src[0].shift) PIN_F(q, in, src[0].C)
     PIN_F(q, in, src[0].H) PIN_F(q, in, src[0].W) PIN_F(q, in, src[0].mode) PIN_F(q, in, src[0].off_y)
     PIN_F(q, in, src[0].off_x)

@@ -379,6 +379,19 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         tile = nxt;
     }
 
+    // ---- two-stage reduction: dump the accumulators as they stand (lane-contiguous 256-B stores) into this
+    // workgroup's slab; wgrad_reduce_kernel sums the split-K slabs.  The float atomics below run at the memory side
+    // at ~1.3 TB/s chip-wide: 38 MB of them per launch cost 25-36 us, the slab stores + the reduction about half.
+    if (p.wsp) {
+        if (!(p.dbg & 1)) {
+            float* wsb = p.wsp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * (NT0 * 16 * 64) + lane;
+#pragma unroll
+            for (int j = 0; j < NT0; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gstore(wsb + (j * 16 + r) * 64, acc[j][r]);
+        }
+        return;
+    }
     // ---- accumulate into dW[co][tap][ci]: lane = ci (128-B contiguous per half wave), regs = co
     const int ci = ci0 + fi * 32 + lr;
     if (ci < p.Cin && !(p.dbg & 1)) {
@@ -396,21 +409,60 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     }
 }
 
+// Second stage: dw[co][tap][ci] += sum over the split-K slabs.  Thread = one accumulator element (block, wave,
+// register, lane) of the first stage's layout, mapped back with the same role arithmetic.
+constexpr int kRedChunk = 8;     // split-K slabs summed per thread of the second stage
+template <int BC, bool kBf16>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
+                                                           int ksplit, int Cout, int Cin, int KS) {
+    const int NTAPS = KS * KS, NT0 = (NTAPS + 1) / 2, per_wave = NT0 * 16 * 64, per_blk = 8 * per_wave;
+    const size_t total = (size_t)nblk * per_blk;
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // blockIdx.y = chunk of kRedChunk slabs: enough threads (and independent loads) in flight also when the channel
+    // block count is 1 and the split-K factor is 256
+    float s = 0.f;
+    const int k0 = blockIdx.y * kRedChunk;
+#pragma unroll
+    for (int k = 0; k < kRedChunk; ++k)
+        if (k0 + k < ksplit) s += ws[(size_t)(k0 + k) * total + idx];
+    const int blk = idx / per_blk, rem = idx - (size_t)blk * per_blk;
+    const int wave = rem / per_wave, jr = (rem - wave * per_wave) >> 6, lane = rem & 63;
+    const int j = jr >> 4, r = jr & 15, lr = lane & 31, lh = lane >> 5;
+    const int ncib = (Cin + BC - 1) / BC, cib = blk % ncib, cob = blk / ncib, co0 = cob * BC, ci0 = cib * BC;
+    const int nfo = kBf16 ? (min(Cout - co0, BC) > 32 ? 2 : 1) : 1, nfi = kBf16 ? (min(Cin - ci0, BC) > 32 ? 2 : 1) : 1;
+    const int npairs = nfo * nfi, pair = (wave & 3) % npairs, tg = wave >> 2;
+    const int fo = pair / nfi, fi = pair % nfi;
+    const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);
+    const int co = co0 + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ci = ci0 + fi * 32 + lr;
+    if (tap < NTAPS && co < Cout && ci < Cin && s != 0.f) atomic_add_f32(dw + ((size_t)co * NTAPS + tap) * Cin + ci, s);
+}
+
 #ifndef MRISR_KERNEL_ONLY
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who);
 int num_cus();
+
+static void wgrad_grid(const ConvParams& p, int BC, int& nblk, int& ksplit) {
+    nblk = ceil_div(p.Cout, BC) * ceil_div(p.Cin, BC);
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x;
+    ksplit = ceil_div(num_cus(), nblk);          // one 8-wave workgroup per CU (LDS-limited)
+    if (ksplit > total_tiles) ksplit = total_tiles;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 65535) ksplit = 65535;
+}
+
+static thread_local size_t p_ws_floats = 0;      // capacity of the caller's workspace for the current call
 
 template <typename T, int SPATIAL, int KS, int FAST = 0>
 static int launch_wgrad(ConvParams& p, hipStream_t s) {
     constexpr int BC = WgTraits<T>::BC;
     const int TW = 1 << p.tw_log2, pad = KS / 2;
     const size_t lds = 2 * (256 * 128 + (size_t)(TW + 2 * pad) * (p.th + 2 * pad) * 128);
-    const int nblk = ceil_div(p.Cout, BC) * ceil_div(p.Cin, BC);
-    const int total_tiles = p.N * p.tiles_y * p.tiles_x;
-    int ksplit = ceil_div(num_cus(), nblk);          // one 8-wave workgroup per CU (LDS-limited)
-    if (ksplit > total_tiles) ksplit = total_tiles;
-    if (ksplit < 1) ksplit = 1;
-    if (ksplit > 65535) ksplit = 65535;
+    int nblk, ksplit;
+    wgrad_grid(p, BC, nblk, ksplit);
+    // two-stage reduction only where it pays: several slabs per output and a workspace that holds them
+    const size_t need = (size_t)nblk * ksplit * 8 * ((KS * KS + 1) / 2) * 16 * 64;
+    if (!(p.wsp && ksplit >= 4 && need <= p_ws_floats)) p.wsp = nullptr;
     auto kern = conv_wgrad_kernel<T, SPATIAL, KS, FAST>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -419,6 +471,11 @@ static int launch_wgrad(ConvParams& p, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3(nblk, ksplit), dim3(kWgThreads), lds, s, p);
     MRISR_CHECK_LAUNCH("conv_wgrad");
+    if (p.wsp) {
+        const size_t total = need / ksplit;
+        wgrad_reduce_kernel<BC, sizeof(T) == 2><<<dim3((unsigned)((total + 255) / 256), ceil_div(ksplit, kRedChunk)), 256, 0, s>>>(p.wsp, p.dw, nblk, ksplit, p.Cout, p.Cin, KS);
+        MRISR_CHECK_LAUNCH("conv_wgrad(reduce)");
+    }
     return MRISR_OK;
 }
 
@@ -444,7 +501,17 @@ static int dispatch_wgrad(ConvParams& p, int spatial, int ks, hipStream_t s) {
     MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_wgrad: 1x1 conv with pooled source");
 }
 
-extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, void* stream) {
+extern "C" size_t mrisr_conv_wgrad_workspace_floats(const mrisr_conv_desc* d) {
+    ConvParams p;
+    if (conv_fill_params(d, p, "conv_wgrad_workspace_floats")) return 0;
+    const int BC = d->dtype == MRISR_BF16 ? 64 : 32;
+    int nblk, ksplit;
+    wgrad_grid(p, BC, nblk, ksplit);
+    return (size_t)nblk * ksplit * 8 * ((d->ksize * d->ksize + 1) / 2) * 16 * 64;
+}
+
+extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, float* workspace,
+                                size_t workspace_floats, void* stream) {
     ConvParams p;
     int rc = conv_fill_params(d, p, "conv_wgrad");
     if (rc) return rc;
@@ -453,6 +520,8 @@ extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float*
     if (d->Cout % vec) MRISR_FAIL(MRISR_E_SHAPE, "conv_wgrad: Cout %d not a multiple of %d", d->Cout, vec);
     p.dy = dy;
     p.dw = dw;
+    p.wsp = workspace;
+    p_ws_floats = workspace ? workspace_floats : 0;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MRISR_BF16) return dispatch_wgrad<bf16_t>(p, d->src[0].spatial, d->ksize, s);
     return dispatch_wgrad<float>(p, d->src[0].spatial, d->ksize, s);

@@ -472,8 +472,13 @@ class UNetEngine:
                 L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st)
                 dy = dyl
             d = self._desc(layer, dt, N, params)
+            need = L.load().mrisr_conv_wgrad_workspace_floats(C.byref(d))
+            ws = getattr(self, "_wgrad_ws", None)
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = self._wgrad_ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
             self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
-                                                    grads[layer.name + ".weight"].data_ptr(), st))
+                                                    grads[layer.name + ".weight"].data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), st))
             if layer.bias and not fuse_bias:
                 L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
                        N * layer.H * layer.W, layer.cout, st)

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--raw", action="store_true", help="RAW source mode instead of NORM")
+    ap.add_argument("--no-ws", action="store_true", help="wgrad: float atomics instead of the two-stage reduction")
     a = ap.parse_args()
     dt = L.BF16 if a.dtype == "bf16" else L.F32
     tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
@@ -100,10 +101,12 @@ def main():
         da = torch.empty(N, H, W, cin, device=dev, dtype=tdt)
         dd.wpacked, dd.out = wpf.data_ptr(), da.data_ptr()
         dw = torch.zeros(cout, ks, ks, cin, device=dev)
+        wsb = None if a.no_ws else torch.empty(max(L.load().mrisr_conv_wgrad_workspace_floats(C.byref(d)), 1), device=dev)
         flops = 2.0 * N * H * W * cin * cout * ks * ks
         calls = {"fwd": lambda: L.call("mrisr_conv_forward", C.byref(d), st),
                  "dgrad": lambda: L.call("mrisr_conv_forward", C.byref(dd), st),
-                 "wgrad": lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), st)}
+                 "wgrad": lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), L.ptr(wsb),
+                                         wsb.numel() if wsb is not None else 0, st)}
         line = f"{name:8s} {cin:4d}->{cout:4d} k{ks} {H:4d}^2 "
         for kind in a.kinds.split(","):
             fn = calls[kind]
