@@ -26,59 +26,84 @@ static GaussWin make_window(float sigma) {   // losses.py:10-18 in fp32
     return w;
 }
 
+// 32 x 32 output tile per block, 4 outputs per thread in both passes (register blocking): the 11-tap windows of
+// 4 neighbouring outputs share 14 inputs, so the LDS reads per output drop from 104 (one output per thread, 32 x 8
+// tile) to 27 and the halo overhead from 2.95x to 1.72x.
+constexpr int kFT = 32;                              // forward tile edge
+constexpr int kFL = kFT + 2 * kHalo;                 // 42
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           double* __restrict__ sums, float* __restrict__ coef, int N,
                                                           int H, int W, float c1, float c2, const GaussWin win) {
-    __shared__ float ta[kLH][kLW + 1], tb[kLH][kLW + 1];
-    __shared__ float hz[5][kLH][kTW + 1];            // horizontally blurred x, y, xx, yy, xy
+    __shared__ float ta[kFL][kFL + 2], tb[kFL][kFL + 2];
+    __shared__ float hz[5][kFL][kFT + 1];            // horizontally blurred x, y, xx, yy, xy
     __shared__ float part[4][2];
     const int t = threadIdx.x, n = blockIdx.z;
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int x0 = blockIdx.x * kFT, y0 = blockIdx.y * kFT;
     const float* an = a + (size_t)n * H * W;
     const float* bn = b + (size_t)n * H * W;
-    for (int i = t; i < kLH * kLW; i += 256) {
-        const int ly = i / kLW, lx = i - ly * kLW;
+    for (int i = t; i < kFL * kFL; i += 256) {
+        const int ly = i / kFL, lx = i - ly * kFL;
         const int gy = y0 + ly - kHalo, gx = x0 + lx - kHalo;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         ta[ly][lx] = in ? an[(size_t)gy * W + gx] : 0.f;
         tb[ly][lx] = in ? bn[(size_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
-    for (int i = t; i < kLH * kTW; i += 256) {
-        const int ly = i / kTW, lx = i - ly * kTW;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    // horizontal pass: segment = 4 consecutive outputs of one staged row (42 rows x 8 segments)
+    for (int sgm = t; sgm < kFL * (kFT / 4); sgm += 256) {
+        const int ly = sgm / (kFT / 4), lx = (sgm - ly * (kFT / 4)) * 4;
+        float u[kWin + 3], v[kWin + 3];
 #pragma unroll
-        for (int k = 0; k < kWin; ++k) {
-            const float u = ta[ly][lx + k], v = tb[ly][lx + k], g = win.g[k];
-            s0 += g * u; s1 += g * v; s2 += g * u * u; s3 += g * v * v; s4 += g * u * v;
+        for (int k = 0; k < kWin + 3; ++k) { u[k] = ta[ly][lx + k]; v[k] = tb[ly][lx + k]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float uu = u[o + k], vv = v[o + k], g = win.g[k];
+                s0 += g * uu; s1 += g * vv; s2 += g * uu * uu; s3 += g * vv * vv; s4 += g * uu * vv;
+            }
+            hz[0][ly][lx + o] = s0; hz[1][ly][lx + o] = s1; hz[2][ly][lx + o] = s2; hz[3][ly][lx + o] = s3; hz[4][ly][lx + o] = s4;
         }
-        hz[0][ly][lx] = s0; hz[1][ly][lx] = s1; hz[2][ly][lx] = s2; hz[3][ly][lx] = s3; hz[4][ly][lx] = s4;
     }
     __syncthreads();
-    const int ly = t / kTW, lx = t - ly * kTW;
-    const int gy = y0 + ly, gx = x0 + lx;
+    // vertical pass: thread = column lx, 4 consecutive output rows ly0..ly0+3
+    const int lx = t & (kFT - 1), ly0 = (t >> 5) * 4;
+    float m[4][5];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) m[o][q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        float col[kWin + 3];
+#pragma unroll
+        for (int k = 0; k < kWin + 3; ++k) col[k] = hz[q][ly0 + k][lx];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) m[o][q] += win.g[k] * col[o + k];
+    }
     float l1 = 0.f, sv = 0.f;
-    if (gy < H && gx < W) {
-        float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int gx = x0 + lx;
 #pragma unroll
-        for (int k = 0; k < kWin; ++k) {
-            const float g = win.g[k];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) m[q] += g * hz[q][ly + k][lx];
-        }
-        const float mu1 = m[0], mu2 = m[1];
-        const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s11 = m[2] - mu1sq, s22 = m[3] - mu2sq, s12 = m[4] - mu12;
-        const float A1 = 2.f * mu12 + c1, A2 = 2.f * s12 + c2, B1 = mu1sq + mu2sq + c1, B2 = s11 + s22 + c2;
-        const float inv = 1.f / (B1 * B2);
-        const float S = A1 * A2 * inv;
-        sv = S;
-        l1 = fabsf(ta[ly + kHalo][lx + kHalo] - tb[ly + kHalo][lx + kHalo]);
-        if (coef) {
-            const size_t plane = (size_t)N * H * W, o = ((size_t)n * H + gy) * W + gx;
-            coef[o] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * S / B1 + 2.f * mu1 * S / B2;
-            coef[plane + o] = -S / B2;
-            coef[2 * plane + o] = 2.f * A1 * inv;
+    for (int o = 0; o < 4; ++o) {
+        const int gy = y0 + ly0 + o;
+        if (gy < H && gx < W) {
+            const float mu1 = m[o][0], mu2 = m[o][1];
+            const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s11 = m[o][2] - mu1sq, s22 = m[o][3] - mu2sq, s12 = m[o][4] - mu12;
+            const float A1 = 2.f * mu12 + c1, A2 = 2.f * s12 + c2, B1 = mu1sq + mu2sq + c1, B2 = s11 + s22 + c2;
+            const float inv = 1.f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            sv += S;
+            l1 += fabsf(ta[ly0 + o + kHalo][lx + kHalo] - tb[ly0 + o + kHalo][lx + kHalo]);
+            if (coef) {
+                const size_t plane = (size_t)N * H * W, oo = ((size_t)n * H + gy) * W + gx;
+                coef[oo] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * S / B1 + 2.f * mu1 * S / B2;
+                coef[plane + oo] = -S / B2;
+                coef[2 * plane + oo] = 2.f * A1 * inv;
+            }
         }
     }
     l1 = wave_sum(l1);
@@ -93,7 +118,7 @@ extern "C" int mrisr_ssim_l1_forward(const float* a, const float* b, double* sum
     if (!a || !b || !sums) MRISR_FAIL(MRISR_E_ARG, "ssim_l1_forward: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "ssim_l1_forward: N%d H%d W%d", N, H, W);
     const float c1 = (0.01f * val_range) * (0.01f * val_range), c2 = (0.03f * val_range) * (0.03f * val_range);
-    dim3 grid(ceil_div(W, kTW), ceil_div(H, kTH), N);
+    dim3 grid(ceil_div(W, kFT), ceil_div(H, kFT), N);
     ssim_l1_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, b, sums, coef, N, H, W, c1, c2, make_window(sigma));
     MRISR_CHECK_LAUNCH("ssim_l1_forward");
     return MRISR_OK;
