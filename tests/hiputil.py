@@ -10,7 +10,6 @@ import torch.nn.functional as F
 from mri_superresolution_amd import _lib as L
 
 DEV = "cuda"
-_WGRAD_CALLS = 0
 
 
 def tdt(dt):
@@ -133,16 +132,14 @@ def conv_forward(dt, srcs, w, H, W, ks, bias=None, combine=L.COMBINE_CONCAT, out
     return nchw(out), stats.cpu().view(L.STAT_SLOTS, N, 8, 2).sum(0)
 
 
-def conv_wgrad(dt, srcs, dy_nchw, cout, cin, H, W, ks, combine=L.COMBINE_CONCAT, alpha=None):
+def conv_wgrad(dt, srcs, dy_nchw, cout, cin, H, W, ks, combine=L.COMBINE_CONCAT, alpha=None, use_ws=False):
     keep = []
     d = make_desc(dt, srcs, H, W, cin, cout, ks, combine, L.OUT_PLAIN, alpha, keep)
     dyd = nhwc(dy_nchw, dt)
     dw = torch.zeros((cout, ks, ks, cin), dtype=torch.float32, device=DEV)
-    # odd-numbered calls go through the two-stage (workspace) reduction, the others through the atomics
-    global _WGRAD_CALLS
-    _WGRAD_CALLS += 1
+    # use_ws: two-stage (workspace) split-K reduction; otherwise float atomics straight into dw
     ws = None
-    if _WGRAD_CALLS & 1:
+    if use_ws:
         nws = L.load().mrisr_conv_wgrad_workspace_floats(C.byref(d))
         ws = torch.empty(max(nws, 1), dtype=torch.float32, device=DEV)
     L.call("mrisr_conv_wgrad", C.byref(d), dyd.data_ptr(), dw.data_ptr(), L.ptr(ws), ws.numel() if ws is not None else 0, stream())

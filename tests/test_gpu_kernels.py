@@ -128,10 +128,15 @@ def test_conv_dgrad_via_flipped_weights(dt, ks):
 
 # ------------------------------------------------------------------------------------------- wgrad
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("case", ["raw", "pool", "up", "concat", "k1"])
-def test_conv_wgrad(dt, case):
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("case", ["raw", "pool", "up", "concat", "k1", "fast1", "fast2", "fast4"])
+def test_conv_wgrad(dt, case, use_ws):
     n = 2
-    if case == "raw":
+    if case.startswith("fast"):     # bf16: the fully unrolled FAST variants (k-step interleave 1 / 2 / 4), several tiles per workgroup
+        cin, cout = {"fast1": (64, 128), "fast2": (64, 32), "fast4": (32, 32)}[case]
+        n, h, w, ks = 3, 40, 72, 3
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=43), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 44))]
+    elif case == "raw":
         cin, cout, h, w, ks = 64, 96, 21, 37, 3
         srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=30), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 31))]
     elif case == "pool":
@@ -148,7 +153,7 @@ def test_conv_wgrad(dt, case):
         cin, cout, h, w, ks = 64, 32, 20, 28, 1
         srcs = [U.SrcSpec(rnd(n, cin, 10, 14, seed=40), L.SRC_NORM, L.SP_UP2, *gn_affine(n, cin, 41))]
     dy = rnd(n, cout, h, w, seed=42)
-    dw = U.conv_wgrad(dt, srcs, dy, cout, cin, h, w, ks)
+    dw = U.conv_wgrad(dt, srcs, dy, cout, cin, h, w, ks, use_ws=use_ws)
     xin = U.ref_conv_input(srcs, dt, h, w).requires_grad_(False)
     wt = torch.zeros(cout, cin, ks, ks, requires_grad=True)
     F.conv2d(xin, wt, padding=ks // 2).backward(U.rounded(dy, dt))
@@ -273,6 +278,76 @@ def test_act_backward(dt, mode):
     assert U.relerr(got, xr.grad) <= tol
     assert U.relerr(dgam.cpu(), gr.grad) <= tol
     assert U.relerr(dbet.cpu(), br.grad) <= tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("mode", ["same", "same2", "pad", "pool", "pool+skip"])
+def test_act_backward_without_g_tensor(dt, mode):
+    """Pass 1 with g = NULL + mrisr_act_bwd_apply_fused (plain consumers, with and without the node's own geometry)
+    and the 2x2-window kernels of max-pooled nodes (even H, W)."""
+    n, c, h, w = 2, 32, 18, 26
+    x = rnd(n, c, h, w, seed=90)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=91), 0.1 * rnd(c, seed=92)
+    scale, shift, mr = _gn_forward_state(x, gamma, beta, dt)
+    xr = U.rounded(x, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    act = F.leaky_relu(F.group_norm(xr, 8, gr, br, 1e-5), 0.2)
+    cons, keep, loss = [], [], 0
+    if mode in ("same", "same2", "pool+skip"):
+        da = rnd(n, c + 8, h, w, seed=93)
+        loss = loss + (act * U.rounded(da, dt)[:, 8:]).sum()
+        cons.append((da, c + 8, 8, h, w, L.SP_NONE, 0, 0))
+    if mode == "same2":
+        db = rnd(n, c, h, w, seed=94)
+        loss = loss + (act * U.rounded(db, dt)).sum()
+        cons.append((db, c, 0, h, w, L.SP_NONE, 0, 0))
+    if mode == "pad":
+        da = rnd(n, c, h + 1, w + 2, seed=95)
+        loss = loss + (F.pad(act, [1, 1, 0, 1]) * U.rounded(da, dt)).sum()
+        cons.append((da, c, 0, h + 1, w + 2, L.SP_NONE, 0, 1))
+    if mode in ("pool", "pool+skip"):
+        dp = rnd(n, c, h // 2, w // 2, seed=96)
+        loss = loss + (F.max_pool2d(act, 2) * U.rounded(dp, dt)).sum()
+        cons.append((dp, c, 0, h // 2, w // 2, L.SP_POOL2, 0, 0))
+    loss.backward()
+    carr = (L.Consumer * 2)()
+    for i, (da, ctot, coff, ch, cw, sp, oy, ox) in enumerate(cons):
+        dd = U.nhwc(da, dt)
+        keep.append(dd)
+        carr[i].da, carr[i].C_total, carr[i].c_off, carr[i].H, carr[i].W = dd.data_ptr(), ctot, coff, ch, cw
+        carr[i].spatial, carr[i].off_y, carr[i].off_x, carr[i].weight_mode = sp, oy, ox, 0
+    xd = U.nhwc(x, dt)
+    red = torch.zeros(n * c * 2, device=U.DEV)
+    L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), len(cons), carr,
+           None, None, red.data_ptr(), None, n, h, w, c, 8, U.stream())
+    dgam, dbet, coef = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.empty(3 * n * c, device=U.DEV)
+    gdev = gamma.to(U.DEV)
+    L.call("mrisr_act_bwd_finalize", red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+           coef.data_ptr(), n, c, 8, float((c // 8) * h * w), None, None, None, 0.0, U.stream())
+    dx = torch.full_like(xd, float("nan"))
+    L.call("mrisr_act_bwd_apply_fused", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), len(cons), carr, None,
+           coef.data_ptr(), dx.data_ptr(), n, h, w, c, U.stream())
+    torch.cuda.synchronize()
+    tol = 3e-4 if dt == L.F32 else 2e-2
+    assert U.relerr(U.nchw(dx), xr.grad) <= tol
+    assert U.relerr(dgam.cpu(), gr.grad) <= tol
+    assert U.relerr(dbet.cpu(), br.grad) <= tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_norm_blend(dt):
+    n, c, h, w = 2, 32, 13, 21
+    x0, x1 = rnd(n, c, h, w, seed=97), rnd(n, c, h, w, seed=98)
+    (s0, t0), (s1, t1) = gn_affine(n, c, 99), gn_affine(n, c, 100)
+    alpha = torch.tensor([0.3])
+    a0 = F.leaky_relu(U.rounded(x0, dt) * s0.view(n, c, 1, 1) + t0.view(n, c, 1, 1), 0.2)
+    a1 = F.leaky_relu(U.rounded(x1, dt) * s1.view(n, c, 1, 1) + t1.view(n, c, 1, 1), 0.2)
+    sg = torch.sigmoid(alpha)
+    ref = sg * a0 + (1 - sg) * a1
+    dev = [U.nhwc(x0, dt), s0.to(U.DEV), t0.to(U.DEV), U.nhwc(x1, dt), s1.to(U.DEV), t1.to(U.DEV), alpha.to(U.DEV)]
+    out = torch.empty_like(dev[0])
+    L.call("mrisr_norm_blend", dt, *[t.data_ptr() for t in dev], out.data_ptr(), n, h, w, c, U.stream())
+    assert U.relerr(U.nchw(out), ref) <= (1e-5 if dt == L.F32 else 1e-2)
 
 
 @pytest.mark.parametrize("dt", DTS)
