@@ -46,3 +46,17 @@ def test_train_then_infer_cli(tmp_path):
     assert Image.open(out_png).size == (80, 64)
     bad = subprocess.run(cmd[:-4] + ["--checkpoint_dir", str(tmp_path / "nope"), "--base_filters", "16"], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1                                   # reference infer.py:448-450
+    # evaluation harness: CSV rows per image x method, exit code contract
+    ev_dir = tmp_path / "eval"
+    cmd = [sys.executable, os.path.join(REPO, "scripts", "evaluate.py"), "--full_res_dir", str(hr_dir), "--low_res_dir", str(lr_dir),
+           "--checkpoint_dir", str(ck), "--base_filters", "16", "--output_dir", str(ev_dir), "--max_images", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import csv
+    rows = list(csv.DictReader(open(ev_dir / "benchmark_results.csv")))
+    assert len(rows) == 12 and {r["method"] for r in rows} == {"bicubic", "bilinear", "sharp_bilinear", "unet"}
+    for r in rows:
+        assert 0.0 <= float(r["ssim"]) <= 1.0 and float(r["psnr"]) > 5.0 and abs(float(r["rmse"]) ** 2 - float(r["mse"])) < 1e-6
+    assert os.path.exists(ev_dir / "summary.txt")
+    bad = subprocess.run(cmd[:-6] + ["--checkpoint_dir", str(tmp_path / "nope")], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1

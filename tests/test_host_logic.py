@@ -181,3 +181,28 @@ def test_data_parallel_bucketed_allreduce_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("OK") == 2
+
+
+def test_evaluation_metrics_and_interpolation_baselines():
+    """scripts/evaluate.py host logic (reference test_comparison.py:92-134,164-202): PSNR guard, the cv2-style
+    half-pixel bilinear / bicubic (a = -0.75) resampling and the 3x3 sharpening."""
+    sys.path.insert(0, REPO)
+    from scripts import evaluate as ev
+    z = np.zeros((8, 8), np.float32)
+    assert ev.psnr(z, z) == 100.0 and abs(ev.psnr(z, z + 0.1) - 20.0) < 1e-4
+    c = np.full((6, 10), 137, np.uint8)
+    for m in ("bilinear", "bicubic", "sharp_bilinear"):
+        up = ev.upscale_array(c, m)
+        assert up.shape == (12, 20) and up.dtype == np.float32 and np.allclose(up, 137 / 255.0)
+    ramp = np.tile((np.arange(16) * 10).astype(np.uint8), (4, 1))
+    bl = ev.upscale_array(ramp, "bilinear") * 255.0
+    # half-pixel centres: output x maps to source (x + 0.5) / 2 - 0.5 -> 2.5 steps, edges replicated
+    assert np.allclose(bl[0, :5], np.rint([0, 2.5, 7.5, 12.5, 17.5])) and bl[0, -1] == 150
+    bc = ev.upscale_array(ramp, "bicubic") * 255.0
+    assert np.allclose(bc[0, 4:28], np.rint(2.5 + 5.0 * np.arange(3, 27)), atol=1.0)     # a cubic kernel reproduces a ramp
+    with pytest.raises(ValueError):
+        ev.upscale_array(c, "lanczos")
+    a = ev.parse_args(["--full_res_dir", "a", "--low_res_dir", "b"])
+    assert (a.base_filters, a.checkpoint_dir, a.output_dir) == (64, "./checkpoints", "./evaluation")
+    rows = [dict(method=m, ssim=0.5, psnr=20.0, mse=0.01, rmse=0.1, mae=0.05, time=0.1, image="x") for m in ev.METHODS]
+    assert set(ev.summarise(rows)) == set(ev.METHODS)
