@@ -38,9 +38,14 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("model storage was re-created (model.to(...) after the optimizer was built)")
         if not m.flat_params.is_cuda:
             raise RuntimeError("FusedAdam runs on the GPU only (no CPU fallback)")
-        for name, p in m.named_parameters():
-            if p.grad is not None and p.grad.data_ptr() != m._grad_views[name].data_ptr():
-                m._grad_views[name].copy_(p.grad)          # foreign gradient tensor: stage it
+        plist = getattr(self, "_plist", None)
+        if plist is None or self._plist_ptr != self._flat_ptr:
+            # (parameter, its view of the flat gradient buffer): cached - named_parameters() walks the module tree
+            plist = self._plist = [(p, m._grad_views[name]) for name, p in m.named_parameters()]
+            self._plist_ptr = self._flat_ptr
+        for p, gv in plist:
+            if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)                            # foreign gradient tensor: stage it
         g = self.param_groups[0]
         self._step += 1
         L.call("mrisr_adam_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
