@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="eval forward only (inference metric; not the headline)")
+    ap.add_argument("--graph", action="store_true", help="with --forward-only: replay the forward as one HIP graph")
     return ap.parse_args()
 
 
@@ -146,6 +147,14 @@ def main():
 
     if args.forward_only:
         model.eval()
+    if args.graph:
+        if not args.forward_only:
+            raise SystemExit("--graph captures the eval forward only (use with --forward-only)")
+        graphed = model.graphed_forward(low)
+        args.no_kernel_timer = True           # events cannot be recorded inside a replayed graph
+
+        def fwd_step():                       # noqa: F811
+            return graphed(low)
     step = fwd_step if args.forward_only else train_step
 
     def sync():
@@ -204,7 +213,8 @@ def main():
             "config": {"workload": f"UNetSuperRes base_filters={args.base_filters} depth=4, {S}x{S} slices -> {2 * S}x{2 * S}, "
                                    f"batch={B}/GPU {args.dtype}, L1+SSIM({args.ssim_weight})"
                                    + (f"+VGG19-perceptual({args.perceptual_weight}, relu5_4, L1, random-init weights), " if perc else ", ")
-                                   + ("eval forward" if args.forward_only else "train step fwd+bwd+Adam+SSIM metric"),
+                                   + (("eval forward" + (" (HIP graph replay)" if args.graph else "")) if args.forward_only
+                                      else "train step fwd+bwd+Adam+SSIM metric"),
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "conv_flops_per_slice": flops_slice,
                        "model_tflops": round(value * flops_slice / 1e12, 2),

@@ -207,3 +207,20 @@ def test_grad_accumulation_and_eval_mode():
     with torch.no_grad():
         o1 = m(low)
     assert o1.shape == (1, 1, 32, 48) and o1.min() >= 0 and o1.max() <= 1 and not o1.requires_grad
+
+
+def test_graphed_forward_matches_eager():
+    """HIP-graph replay of the eval forward (UNetSuperRes.graphed_forward) reproduces the eager launch sequence."""
+    m = _model(16, 3, torch.float32).eval()
+    low, _ = make_pair(2, 24, 40, 21)
+    low2, _ = make_pair(2, 24, 40, 22)
+    with torch.no_grad():
+        ref1, ref2 = m(low.cuda()).clone(), m(low2.cuda()).clone()
+    run = m.graphed_forward(low.cuda())
+    assert torch.equal(run(low.cuda()), ref1)
+    assert torch.equal(run(low2.cuda()), ref2)
+    assert torch.equal(run(low.cuda()), ref1)
+    with pytest.raises(ValueError):
+        run(torch.zeros(1, 1, 24, 40, device="cuda"))
+    with pytest.raises(RuntimeError):
+        m.train().graphed_forward(low.cuda())
