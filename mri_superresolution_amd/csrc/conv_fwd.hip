@@ -5,11 +5,13 @@
 // (:52), bilinear Upsample (:71,151), torch.cat (:93), PixelShuffle (:102) and the alpha blend
 // (:206-207) folded into the operand loader / epilogue so none of those tensors is materialised.
 //
-// Decomposition: one workgroup (4 waves) = 256 output pixels (TH x TW tile of one image) x BN output
-// channels.  K loop = cin chunks of 64 bytes; per chunk the transformed (TH+2)x(TW+2) halo tile and the
-// 9 x BN x 64 B weight image are staged in LDS once and re-used by all 9 taps (LDS-tiled direct conv on
-// MFMA).  D = W(BN x K) * X(K x pixels): the accumulator has a pixel per lane and 4 consecutive output
-// channels per register quad, so NHWC stores are 8/16-byte pieces.
+// Decomposition: a work item = 256 output pixels (TH x TW tile of one image) x BN output channels x one cin
+// chunk of 64 bytes; per item the transformed (TH+2)x(TW+2) halo tile (and, unless all chunks' weights are
+// LDS-resident, the 9 x BN x 64 B weight image) is staged in LDS once and re-used by all 9 taps (LDS-tiled
+// direct conv on MFMA).  D = W(BN x K) * X(K x pixels): the accumulator has a pixel per lane and 4 consecutive
+// output channels per register quad, so NHWC stores are 8/16-byte pieces.  A persistent 8-wave workgroup runs
+// two such item streams in antiphase (see conv_igemm_kernel).  The materialised exceptions to "nothing is
+// materialised" (pooled / upsampled / blended inputs of the narrow layers) are listed in DESIGN.md section 3.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -54,10 +56,10 @@ constexpr int kEpiMask = 2;         // template-only epilogue kind: plain store 
 
 // Work decomposition: a persistent 8-wave workgroup owns one cout block (BN channels) and a contiguous range
 // of 256-pixel tiles.  Its two halves (waves 0-3 / 4-7) each walk their own tiles; a work item is (tile, cin
-// chunk of 64 B).  In every tick one half runs the MFMAs of its current item (and issues the global loads of
-// its next one) while the other half does the VALU work: epilogue of a finished tile, GroupNorm+LeakyReLU
-// transform and LDS commit of its next item.  The workgroup barrier at the end of a tick swaps the roles, so
-// each SIMD always has one matrix wave and one vector wave.
+// chunk of 64 B).  In every tick one half runs the MFMAs of its current item while the other half does the vector
+// work: GroupNorm+LeakyReLU transform and LDS commit of its next item, the global loads of the item after that,
+// then the epilogue of a finished tile.  The workgroup barrier at the end of a tick swaps the roles, so each SIMD
+// always has one matrix wave and one vector wave.
 template <typename T, int BN, int SPATIAL, int KS, bool WS, int EPI>
 __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
