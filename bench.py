@@ -70,6 +70,12 @@ def cpu_baseline(base_filters, size, ssim_weight):
                       f"batch {batch}, L1+SSIM({ssim_weight}), 1 warm-up + {n} timed steps, {dt / n * 1e3:.0f} ms/step"}
 
 
+def unet_flops_fwd(f, H, W):
+    """Convolution FLOPs (2*MAC) of one UNetSuperRes forward per sample, input H x W:
+    F = 18 f^2 HW (20 + 1/6 + (11/9)/f)."""
+    return 18.0 * f * f * H * W * (20.0 + 1.0 / 6.0 + (11.0 / 9.0) / f)
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
     tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, with the gfx950
@@ -104,7 +110,6 @@ def main():
     from mri_superresolution_amd.optim import FusedAdam
     from mri_superresolution_amd.parallel import DataParallel
     from mri_superresolution_amd.utils.losses import SSIM, CombinedLoss
-    from oracle.unet_ref import unet_flops_fwd        # FLOP formula only
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
