@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=256, help="network input H=W (output is 2x)")
     ap.add_argument("--base-filters", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=4, help="resolution levels (4 = the reference; 5 = BASELINE config 5, an extension)")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--ssim-weight", type=float, default=0.4)
     ap.add_argument("--perceptual-weight", type=float, default=0.0,
@@ -70,10 +71,13 @@ def cpu_baseline(base_filters, size, ssim_weight):
                       f"batch {batch}, L1+SSIM({ssim_weight}), 1 warm-up + {n} timed steps, {dt / n * 1e3:.0f} ms/step"}
 
 
-def unet_flops_fwd(f, H, W):
+def unet_flops_fwd(f, H, W, depth=4):
     """Convolution FLOPs (2*MAC) of one UNetSuperRes forward per sample, input H x W:
-    F = 18 f^2 HW (20 + 1/6 + (11/9)/f)."""
-    return 18.0 * f * f * H * W * (20.0 + 1.0 / 6.0 + (11.0 / 9.0) / f)
+    F = 18 f^2 HW (20 + 1/6 + (11/9)/f) at the reference's depth 4; other depths by the same per-layer count
+    (U = 18 f^2 HW: inc = U/f + U, each Down 1.5 U, each Up (2/9 + 3) U, head 5 U + (2/(9f)) U - every Down / Up
+    block costs the same because channels double as the pixel count quarters)."""
+    U = 18.0 * f * f * H * W
+    return U * (1.0 / f + 1.0 + (depth - 1) * 1.5 + (depth - 1) * (2.0 / 9.0 + 3.0) + 5.0 + 2.0 / (9.0 * f))
 
 
 def pmc_traffic(kernel):
@@ -113,7 +117,7 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = UNetSuperRes(1, 1, args.base_filters).to(dev).set_compute_dtype(dtype).train()
+    model = UNetSuperRes(1, 1, args.base_filters, depth=args.depth).to(dev).set_compute_dtype(dtype).train()
     opt = FusedAdam(model, lr=1e-4, weight_decay=1e-5)
     import warnings
     with warnings.catch_warnings():
@@ -205,7 +209,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        f_fwd = unet_flops_fwd(args.base_filters, S, S)
+        f_fwd = unet_flops_fwd(args.base_filters, S, S, args.depth)
         flops_slice = f_fwd if args.forward_only else 3.0 * f_fwd
         perc = args.perceptual_weight > 0 and not args.forward_only
         if perc:      # VGG19 features[:36] at the 2Sx2S output: 777,600 FLOP/pixel forward; gen + target + dgrad
@@ -215,7 +219,7 @@ def main():
             "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"UNetSuperRes base_filters={args.base_filters} depth=4, {S}x{S} slices -> {2 * S}x{2 * S}, "
+            "config": {"workload": f"UNetSuperRes base_filters={args.base_filters} depth={args.depth}, {S}x{S} slices -> {2 * S}x{2 * S}, "
                                    f"batch={B}/GPU {args.dtype}, L1+SSIM({args.ssim_weight})"
                                    + (f"+VGG19-perceptual({args.perceptual_weight}, relu5_4, L1, random-init weights), " if perc else ", ")
                                    + (("eval forward" + (" (HIP graph replay)" if args.graph else "")) if args.forward_only

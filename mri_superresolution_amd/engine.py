@@ -113,7 +113,7 @@ class UNetEngine:
     """Executes UNetSuperRes on one GPU.  ``params``: dict key -> fp32 tensor (conv weights in
     channels_last storage, i.e. physically [Cout][kh][kw][Cin]); ``grads``: same keys."""
 
-    def __init__(self, base_filters: int, in_channels: int = 1, out_channels: int = 1):
+    def __init__(self, base_filters: int, in_channels: int = 1, out_channels: int = 1, depth: int = 4):
         if in_channels != 1 or out_channels != 1:
             raise NotImplementedError("the HIP path implements the reference's 1->1 channel configuration "
                                       "(scripts/train.py:167-173, scripts/infer.py:46-51)")
@@ -139,12 +139,17 @@ class UNetEngine:
         self.stem = node("inc.double_conv.0", f, "inc.double_conv.1.weight", "inc.double_conv.1.bias")
         x1 = node("inc.double_conv.3", f, "inc.double_conv.4.weight", "inc.double_conv.4.bias")
         self.layers.append(Layer("inc.double_conv.3", f, f, 3, [Source(self.stem)], x1))
-        x2 = dconv("down1.maxpool_conv.1", [Source(x1)], f, 2 * f, pool_src=True)
-        x3 = dconv("down2.maxpool_conv.1", [Source(x2)], 2 * f, 4 * f, pool_src=True)
-        x4 = dconv("down3.maxpool_conv.1", [Source(x3)], 4 * f, 8 * f, pool_src=True)
+        # depth resolution levels: 4 = the reference (unet_model.py:137-146); other values are this build's extension
+        if depth < 2:
+            raise ValueError("depth must be >= 2")
+        self.depth = depth
+        xs = [x1]
+        for k in range(1, depth):
+            xs.append(dconv(f"down{k}.maxpool_conv.1", [Source(xs[-1])], f * 2 ** (k - 1), f * 2 ** k, pool_src=True))
         # decoder (unet_model.py:144-146, 70-94)
-        u = x4
-        for j, (skip, cout) in enumerate(((x3, 4 * f), (x2, 2 * f), (x1, f)), start=1):
+        u = xs[-1]
+        for j in range(1, depth):
+            skip, cout = xs[depth - 1 - j], f * 2 ** (depth - 1 - j)
             up = node(f"up{j}.up.1", cout, f"up{j}.up.2.weight", f"up{j}.up.2.bias")
             # Upsample -> conv1x1 (unet_model.py:71-72) runs as conv1x1 at low resolution -> bilinear x2 (linear ops
             # commute): 4x fewer conv FLOPs and no gather inside the conv loader
@@ -272,8 +277,9 @@ class UNetEngine:
         dt = _dt(dtype)
         dev = x.device
         N, _, H, W = x.shape
-        if H < 8 or W < 8:
-            raise ValueError("input must be at least 8x8 (three 2x2 max-pools)")
+        mins = 2 ** (self.depth - 1)
+        if H < mins or W < mins:
+            raise ValueError(f"input must be at least {mins}x{mins} ({self.depth - 1} 2x2 max-pools)")
         st = L.stream_ptr()
         f = self.f
         nodes = list(self.nodes.values())

@@ -124,19 +124,24 @@ class UNetSuperRes(nn.Module):
     (alpha is given in percent and stored as ``initial_alpha / 100``).
     """
 
-    def __init__(self, in_channels=1, out_channels=1, base_filters=32, initial_alpha=0.0):
+    def __init__(self, in_channels=1, out_channels=1, base_filters=32, initial_alpha=0.0, *, depth=4):
         super().__init__()
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.base_filters = base_filters
+        # depth = resolution levels.  4 = the reference, where it is hard-wired (unet_model.py:136-146); any other value
+        # is this build's keyword-only extension (BASELINE config 5: depth=5) and changes the state_dict keys
+        # (down1..down{depth-1}, up1..up{depth-1}).
+        if depth < 2:
+            raise ValueError("depth must be >= 2")
+        self.depth = depth
         f = base_filters
         self.inc = DoubleConv(in_channels, f)
-        self.down1 = Down(f, f * 2)
-        self.down2 = Down(f * 2, f * 4)
-        self.down3 = Down(f * 4, f * 8)
-        self.up1 = Up(f * 8, f * 4, f * 4)
-        self.up2 = Up(f * 4, f * 2, f * 2)
-        self.up3 = Up(f * 2, f, f)
+        for k in range(1, depth):
+            setattr(self, f"down{k}", Down(f * 2 ** (k - 1), f * 2 ** k))
+        for j in range(1, depth):
+            cout = f * 2 ** (depth - 1 - j)
+            setattr(self, f"up{j}", Up(2 * cout, cout, cout))
         self.final_up_bilinear = nn.Sequential(
             nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
             nn.Conv2d(f, f // 2, kernel_size=3, padding=1, bias=False),
@@ -152,7 +157,7 @@ class UNetSuperRes(nn.Module):
             nn.Conv2d(f // 2, out_channels, kernel_size=1),
         )
         self._initialize_weights()
-        self._engine = UNetEngine(base_filters, in_channels, out_channels)
+        self._engine = UNetEngine(base_filters, in_channels, out_channels, depth)
         self.compute_dtype = None          # None: bf16 under torch.autocast, else fp32
         self.grad_ready_hook = None        # callable(layer_name) for data-parallel overlap
         self.flat_params = None

@@ -20,10 +20,13 @@ LRELU_SLOPE = 0.2      # unet_model.py:31,37,74,104,154,170
 
 
 # --------------------------------------------------------------------------- spec
-def state_dict_spec(base_filters: int = 32, in_channels: int = 1, out_channels: int = 1):
+def state_dict_spec(base_filters: int = 32, in_channels: int = 1, out_channels: int = 1, depth: int = 4):
     """Ordered ``key -> shape`` of the 64 parameter tensors (unet_model.py:129-173).
 
     Order is ``nn.Module.state_dict()`` order of the reference (registration order).
+    ``depth`` = number of resolution levels; 4 is the reference (hard-wired there).  Other values are
+    the build's keyword-only extension for BASELINE config 5 (``depth=5``): ``inc`` + (depth-1) ``Down`` blocks +
+    (depth-1) ``Up`` blocks, generalising unet_model.py:136-146 - no reference counterpart, hence unpinned.
     """
     f = base_filters
     spec = OrderedDict()
@@ -38,9 +41,12 @@ def state_dict_spec(base_filters: int = 32, in_channels: int = 1, out_channels: 
         spec[f"{prefix}.double_conv.4.bias"] = (cout,)
 
     dconv("inc", in_channels, f)
-    for k in (1, 2, 3):
+    if depth < 2:
+        raise ValueError("depth must be >= 2")
+    for k in range(1, depth):
         dconv(f"down{k}.maxpool_conv.1", f * 2 ** (k - 1), f * 2 ** k)
-    for j, cout in ((1, 4 * f), (2, 2 * f), (3, f)):
+    for j in range(1, depth):
+        cout = f * 2 ** (depth - 1 - j)
         spec[f"up{j}.up.1.weight"] = (cout, 2 * cout, 1, 1)
         spec[f"up{j}.up.2.weight"] = (cout,)
         spec[f"up{j}.up.2.bias"] = (cout,)
@@ -61,7 +67,7 @@ def state_dict_spec(base_filters: int = 32, in_channels: int = 1, out_channels: 
 
 
 def formula_state_dict(base_filters: int, seed: int = 0, in_channels: int = 1,
-                       out_channels: int = 1, alpha: float = 0.3):
+                       out_channels: int = 1, alpha: float = 0.3, depth: int = 4):
     """Deterministic, file-free weights used by the golden fixtures and the tests.
 
     Conv weights ~ N(0, 2/(Cout*k*k)) (the scale of unet_model.py:181), conv biases
@@ -70,7 +76,7 @@ def formula_state_dict(base_filters: int, seed: int = 0, in_channels: int = 1,
     numpy's PCG64 (stable across versions) one key at a time.
     """
     sd = OrderedDict()
-    for i, (key, shape) in enumerate(state_dict_spec(base_filters, in_channels, out_channels).items()):
+    for i, (key, shape) in enumerate(state_dict_spec(base_filters, in_channels, out_channels, depth).items()):
         rng = np.random.Generator(np.random.PCG64(seed * 1000 + i))
         if key == "alpha":
             v = np.asarray(alpha, dtype=np.float32)
@@ -136,16 +142,20 @@ def _up(sd, p, x1, x2, taps=None):
     return _double_conv(sd, f"{p}.conv", torch.cat([x2, x1], dim=1), taps)
 
 
-def unet_forward(sd, x, taps=None):
+def unet_forward(sd, x, taps=None, depth: int = 4):
     """``UNetSuperRes.forward`` (unet_model.py:189-211).  ``taps`` (optional dict) receives
-    the raw (pre-GroupNorm) output of every convolution plus the stage activations."""
-    x1 = _double_conv(sd, "inc", x, taps)
-    x2 = _double_conv(sd, "down1.maxpool_conv.1", F.max_pool2d(x1, 2), taps)
-    x3 = _double_conv(sd, "down2.maxpool_conv.1", F.max_pool2d(x2, 2), taps)
-    x4 = _double_conv(sd, "down3.maxpool_conv.1", F.max_pool2d(x3, 2), taps)
-    u = _up(sd, "up1", x4, x3, taps)
-    u = _up(sd, "up2", u, x2, taps)
-    u = _up(sd, "up3", u, x1, taps)
+    the raw (pre-GroupNorm) output of every convolution plus the stage activations.
+    ``depth`` != 4: the build's extension (see state_dict_spec)."""
+    xs = [_double_conv(sd, "inc", x, taps)]
+    for k in range(1, depth):
+        xs.append(_double_conv(sd, f"down{k}.maxpool_conv.1", F.max_pool2d(xs[-1], 2), taps))
+    u = xs[-1]
+    for j in range(1, depth):
+        u = _up(sd, f"up{j}", u, xs[depth - 1 - j], taps)
+    x1 = xs[0]
+    x2 = xs[1] if depth > 1 else None
+    x3 = xs[2] if depth > 2 else None
+    x4 = xs[3] if depth > 3 else None
     # dual-branch 2x head (unet_model.py:150-158, 202-207)
     yb = F.conv2d(F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=True),
                   sd["final_up_bilinear.1.weight"], None, padding=1)
@@ -160,7 +170,8 @@ def unet_forward(sd, x, taps=None):
     xf = _gn_lrelu(yf, sd["final_conv.1.weight"], sd["final_conv.1.bias"])
     yo = F.conv2d(xf, sd["final_conv.3.weight"], sd["final_conv.3.bias"])
     if taps is not None:
-        taps.update({"x1": x1, "x2": x2, "x3": x3, "x4": x4, "up3": u,
+        taps.update({k: v for k, v in (("x1", x1), ("x2", x2), ("x3", x3), ("x4", x4)) if v is not None})
+        taps.update({f"up{depth - 1}": u,
                      "final_up_bilinear.1": yb, "final_up_pixelshuffle.conv": yc,
                      "final_up_pixelshuffle.shuffled": yp,
                      "blend": xm, "final_conv.0": yf, "final_conv.3": yo})

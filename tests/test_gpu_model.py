@@ -224,3 +224,37 @@ def test_graphed_forward_matches_eager():
         run(torch.zeros(1, 1, 24, 40, device="cuda"))
     with pytest.raises(RuntimeError):
         m.train().graphed_forward(low.cuda())
+
+
+@pytest.mark.parametrize("depth", [3, 5])
+def test_depth_extension_matches_generalised_oracle(depth):
+    """``UNetSuperRes(..., depth=d)`` (keyword-only extension for BASELINE config 5; the reference hard-wires 4
+    resolution levels, so this is checked against the oracle generalised from unet_model.py:136-146 - unpinned by the
+    reference itself).  The float64 run of the oracle is the arbiter: fp32 forward <= 1e-3 relative, loss <= 2e-5,
+    every gradient <= 5e-4 of its max + 1e-6 absolute (a scalar bias gradient is a cancelling sum of ~6000 terms of
+    magnitude 1e-4: final_conv.3.bias at depth 3 has |g| = 1.1e-3 and an fp32 summation noise of 6e-7)."""
+    f, n, h, w, seed = 16, 2, 32, 48, 4
+    sd = formula_state_dict(f, seed, depth=depth)
+    low, high = make_pair(n, h, w, seed)
+    ref_out, ref_loss, ref_grads = loss_and_grads({k: v.double() for k, v in sd.items()}, low.double(), high.double(),
+                                                  0.4, depth=depth)
+    m = UNetSuperRes(1, 1, f, depth=depth)
+    assert list(m.state_dict().keys()) == list(sd.keys()) and m.depth == depth
+    m.load_state_dict(sd)
+    m = m.cuda().set_compute_dtype(torch.float32).train()
+    out = m(low.cuda())
+    loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(out, high.cuda())
+    loss.backward()
+    rel = ((out.detach().cpu().double() - ref_out).abs() / ref_out.abs().clamp_min(1e-2)).max().item()
+    assert rel <= 1e-3, rel
+    assert abs(loss.item() - float(ref_loss)) <= 2e-5
+    worst = 0.0
+    for k, p in m.named_parameters():
+        r = ref_grads[k]
+        err = (p.grad.cpu().double() - r).abs().max().item()
+        assert err <= 5e-4 * r.abs().max().item() + 1e-6, f"{k}: err {err:.3e} vs max {r.abs().max().item():.3e}"
+        worst = max(worst, err / (r.abs().max().item() + 2e-3))
+    _report(f"depth={depth} fp32 vs f64 oracle: out rel err {rel:.2e}, loss err {abs(loss.item() - float(ref_loss)):.2e}, "
+            f"worst grad err/(max+2e-3) {worst:.2e}")
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 2 ** (depth - 2), 64, device="cuda"))

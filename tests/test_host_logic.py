@@ -206,3 +206,18 @@ def test_evaluation_metrics_and_interpolation_baselines():
     assert (a.base_filters, a.checkpoint_dir, a.output_dir) == (64, "./checkpoints", "./evaluation")
     rows = [dict(method=m, ssim=0.5, psnr=20.0, mse=0.01, rmse=0.1, mae=0.05, time=0.1, image="x") for m in ev.METHODS]
     assert set(ev.summarise(rows)) == set(ev.METHODS)
+
+
+def test_depth_extension_contract():
+    """depth is keyword-only, 4 reproduces the reference's 64 keys, other depths follow the generalised spec."""
+    from mri_superresolution_amd.models.unet_model import UNetSuperRes
+    from oracle.unet_ref import state_dict_spec
+    with pytest.raises(TypeError):
+        UNetSuperRes(1, 1, 16, 0.0, 5)
+    assert list(UNetSuperRes(1, 1, 16).state_dict()) == list(state_dict_spec(16)) and len(state_dict_spec(16)) == 64
+    for d in (2, 3, 5):
+        m = UNetSuperRes(1, 1, 16, depth=d)
+        spec = state_dict_spec(16, depth=d)
+        assert list(m.state_dict()) == list(spec) and all(tuple(v.shape) == tuple(spec[k]) for k, v in m.state_dict().items())
+    with pytest.raises(ValueError):
+        UNetSuperRes(1, 1, 16, depth=1)
