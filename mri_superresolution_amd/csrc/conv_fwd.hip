@@ -60,6 +60,20 @@ constexpr int kEpiMask = 2;         // template-only epilogue kind: plain store 
 // work: GroupNorm+LeakyReLU transform and LDS commit of its next item, the global loads of the item after that,
 // then the epilogue of a finished tile.  The workgroup barrier at the end of a tick swaps the roles, so each SIMD
 // always has one matrix wave and one vector wave.
+// Phase profile (tuning builds only, -DMRISR_PHASE_TIMING, tools/build_prof.sh + tools/conv_bench.py): s_memtime stamps
+// around the parts of a tick, accumulated in SGPRs by wave 0 of each half of the middle workgroup.  Not compiled into
+// libmrisr.so.
+#ifdef MRISR_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[2][12];
+#define PT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime();
+#define PT_MARK(k) { const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t; pt_t = pt_now; }
+#define PT_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0f70)   /* vmcnt(0) only (gfx9 encoding: lgkmcnt 15, expcnt 7) */
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#define PT_WAIT_LOADS()
+#endif
+
 template <typename T, int BN, int SPATIAL, int KS, bool WS, int EPI>
 __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -467,9 +481,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         issue_weights(0);
         issue(cur_n, 0);
     }
+    PT_DECL
     for (int tick = 0; tick < nticks; ++tick) {
         const int phase = tick - half;
         const int c = phase >> 1;
+        PT_MARK(8)
         if (phase >= 0 && (phase & 1) == 0) {
             // ------------------------------------------------ vector phase
             // Order: commit item c (its loads were issued one full tick pair ago) -> issue the loads of item c+1
@@ -478,7 +494,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             // to land; issued at the start of the matrix phase they had half of that and the commit stalled on
             // vmcnt (measured: 20-40 us per launch).
             if (c < nitems) {
+                PT_WAIT_LOADS();
+                PT_MARK(0)
                 commit(cur_n, cur_kc, cur_ty0, cur_tx0);
+                PT_MARK(1)
                 nxt_tile = cur_tile; nxt_kc = cur_kc + 1; nxt_n = cur_n; nxt_ty0 = cur_ty0; nxt_tx0 = cur_tx0;
                 if (nxt_kc == p.nchunks) {
                     nxt_kc = 0;
@@ -488,12 +507,16 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         set_geom(nxt_n, nxt_ty0, nxt_tx0);
                     }
                 }
+                PT_MARK(2)
                 issue(nxt_n, nxt_kc);     // unconditional: after the last item this re-loads valid addresses and is never committed
+                PT_MARK(3)
             }
             if (ep_pending) {
                 epilogue(ep_n, ep_ty0, ep_tx0);
+                PT_MARK(4)
                 if (p.stats && (c >= nitems || cur_n != ep_n)) flush_stats(ep_n);
                 ep_pending = false;
+                PT_MARK(9)
             }
         } else if (phase >= 0 && c < nitems) {
             // ------------------------------------------------ matrix phase
@@ -527,12 +550,27 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 ep_n = cur_n; ep_ty0 = cur_ty0; ep_tx0 = cur_tx0;
             }
             cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
+            PT_MARK(6)
         }
         if (!(p.dbg & 64)) __syncthreads();
+#ifdef MRISR_PHASE_TIMING
+        if (phase >= 0 && (phase & 1) == 0) PT_MARK(5) else PT_MARK(7)
+#endif
     }
+#ifdef MRISR_PHASE_TIMING
+    if (blockIdx.x == gridDim.x / 2 && (t == 0)) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) g_phase_cycles[half][k] = pt_acc[k];
+    }
+#endif
 }
 
 #ifndef MRISR_KERNEL_ONLY   // (tuning: a translation unit that instantiates single kernels includes this file with it set)
+#ifdef MRISR_PHASE_TIMING
+extern "C" int mrisr_debug_phase_cycles(unsigned long long* out24) {
+    return (int)hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 24);
+}
+#endif
 // ------------------------------------------------------------------------------------------------
 // Weight packer: fp32 [Cout][k][k][Cin] -> sequence of LDS images [cout block][cin chunk][tap][BN][64 B]
 // (swizzled exactly as the kernel reads them).  transpose_flip: the dgrad operand, i.e. the image of

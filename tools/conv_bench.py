@@ -121,6 +121,16 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             tot[kind] = tot.get(kind, 0.0) + us
             line += f"| {kind} {us:8.1f} us {flops / us / 1e6:7.1f} TF/s "
+            if kind != "wgrad" and hasattr(L.load(), "mrisr_debug_phase_cycles"):
+                # profiling build (tools/build_prof.sh, MRISR_LIB=...): s_memtime cycles of the middle workgroup's
+                # two halves in the last launch: load wait, commit, issue, epilogue, barrier (vector side), MFMA block,
+                # barrier (matrix side), loop overhead
+                buf = (C.c_ulonglong * 24)()
+                L.load().mrisr_debug_phase_cycles(buf)
+                names = ["ldwait", "commit", "geom", "issue", "epilog", "bar_v", "mfma", "bar_m", "loop", "flush", "-", "-"]
+                for h in range(2):
+                    v = [buf[12 * h + k] for k in range(10)]
+                    line += f"\n      half{h} cycles total {sum(v):8d}: " + " ".join(f"{n}={x}" for n, x in zip(names, v))
         print(line, flush=True)
     print("total us per kind:", {k: round(v, 1) for k, v in tot.items()})
 
