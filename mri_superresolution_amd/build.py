@@ -20,6 +20,9 @@ LIB = os.path.join(HERE, "libmrisr.so")
 SOURCES = ["api.cpp", "conv_fwd.hip", "conv_wgrad.hip", "norm.hip", "head_stem.hip", "loss.hip", "optim.hip", "vgg.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# conv_fwd.hip: no SLP vectorisation - it turns the epilogue's statistics into v_pk_*_f32 ops plus register shuffles, and
+# packed fp32 ops issue at half speed next to the other wave's MFMA block (measured with the phase profile)
+FILE_FLAGS = {"conv_fwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps_mtime():
@@ -33,7 +36,7 @@ def _compile(src, force):
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

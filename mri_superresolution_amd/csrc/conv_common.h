@@ -43,6 +43,7 @@ struct SrcDev {
     const float* scale;
     const float* shift;
     int C, H, W, mode, off_y, off_x;
+    unsigned img_bytes;   // H * W * C * sizeof(T): byte stride between images (host-checked < 2^32)
 };
 
 struct ConvParams {
@@ -76,11 +77,24 @@ __device__ __forceinline__ ConvParams pin_params(const ConvParams& in) {
     PIN_F(q, in, dy) PIN_F(q, in, dw) PIN_F(q, in, wsp) PIN_F(q, in, mask) PIN_F(q, in, Cin) PIN_F(q, in, combine)
     PIN_F(q, in, src[0].ptr) PIN_F(q, in, src[0].scale) PIN_F(q, in, src[0].shift) PIN_F(q, in, src[0].C)
     PIN_F(q, in, src[0].H) PIN_F(q, in, src[0].W) PIN_F(q, in, src[0].mode) PIN_F(q, in, src[0].off_y)
-    PIN_F(q, in, src[0].off_x)
+    PIN_F(q, in, src[0].off_x) PIN_F(q, in, src[0].img_bytes)
     PIN_F(q, in, src[1].ptr) PIN_F(q, in, src[1].scale) PIN_F(q, in, src[1].shift) PIN_F(q, in, src[1].C)
     PIN_F(q, in, src[1].H) PIN_F(q, in, src[1].W) PIN_F(q, in, src[1].mode) PIN_F(q, in, src[1].off_y)
-    PIN_F(q, in, src[1].off_x)
+    PIN_F(q, in, src[1].off_x) PIN_F(q, in, src[1].img_bytes)
     return q;
+}
+
+// Scalar (SALU) base of image n of a source, and the 24-bit multiply-add the per-lane byte offsets are made of
+// (inline asm: hipcc otherwise widens these to 64-bit VALU multiplies, v_mad_u64_u32 / v_mul_lo_u32, quarter rate).
+__device__ __forceinline__ const char* image_base(const void* ptr, int n, unsigned img_bytes) {
+    unsigned lo, hi;
+    asm("s_mul_i32 %0, %2, %3\n\ts_mul_hi_u32 %1, %2, %3" : "=&s"(lo), "=s"(hi) : "s"(n), "s"(img_bytes));
+    return (const char*)ptr + (((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {   // (a & 0xffffff) * (b & 0xffffff) + c
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // Per-thread precomputed geometry of the halo pixels this thread stages (same for every cin chunk).

@@ -47,6 +47,7 @@ struct Prefetch {
     float sc[Vec16<T>::N], sh[Vec16<T>::N];       // GroupNorm affine of the chunk's channels (source 0 / the only one)
     float sc1[NH == 2 ? Vec16<T>::N : 1], sh1[NH == 2 ? Vec16<T>::N : 1];   // blend: source 1
     int mask, mode;
+    bool ok[kMaxHaloIter];                        // NH == 1: slot holds an in-image pixel of an existing channel (else: zero)
     float slope;                                  // NH == 1: activation as max(y, slope*y): 0.2 NORM, 1 RAW, 0 RELU
 };
 
@@ -61,10 +62,10 @@ constexpr int kEpiMask = 2;         // template-only epilogue kind: plain store 
 // then the epilogue of a finished tile.  The workgroup barrier at the end of a tick swaps the roles, so each SIMD
 // always has one matrix wave and one vector wave.
 // Phase profile (tuning builds only, -DMRISR_PHASE_TIMING, tools/build_prof.sh + tools/conv_bench.py): s_memtime stamps
-// around the parts of a tick, accumulated in SGPRs by wave 0 of each half of the middle workgroup.  Not compiled into
+// around the parts of a tick, accumulated in SGPRs by every wave of the middle workgroup.  Not compiled into
 // libmrisr.so.
 #ifdef MRISR_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[2][12];
+__device__ unsigned long long g_phase_cycles[8][12];
 #define PT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime();
 #define PT_MARK(k) { const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t; pt_t = pt_now; }
 #define PT_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0f70)   /* vmcnt(0) only (gfx9 encoding: lgkmcnt 15, expcnt 7) */
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     int upflags = 0;      // UP2 gather prefetch: bit 2i = second row differs, bit 2i+1 = second column differs
     auto set_geom = [&](int n, int ty0, int tx0) {
         if (p.dbg & 32) return;
+        if constexpr (NH == 1) return;     // plain loader: addresses are derived per item from scalars (see issue)
 #pragma unroll
         for (int i = 0; i < kMaxHaloIter; ++i)
             halo_geom_yx<GSP>(geom, i, hyx[i] >> 16, hyx[i] & 0xffff, hyx[i] >= 0, PAD, n, ty0, tx0, p);
@@ -202,37 +204,54 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
         }
     };
-    auto issue = [&](int n, int kc) {
+    auto issue = [&](int n, int kc, int ty0, int tx0) {
         if (p.dbg & 4) return;
+        if constexpr (NH == 1) {
+            // Plain loader.  Everything is derived per item from wave-uniform scalars (image, tile origin, chunk: SALU
+            // after the readfirstlanes) and the packed halo-slot coordinates: no per-tile geometry registers, no 64-bit
+            // per-lane multiplies.  Address = scalar image base of the lane's source + a 32-bit byte offset
+            // (y * W + x) * C * sizeof(T) + channel bytes from two 24-bit mads (host-checked ranges).  Every slot loads
+            // (out-of-image / padding slots from the image base, a valid address); their validity travels as a lane mask.
+            const int ns = __builtin_amdgcn_readfirstlane(n), kcs = __builtin_amdgcn_readfirstlane(kc);
+            const int ty0s = __builtin_amdgcn_readfirstlane(ty0), tx0s = __builtin_amdgcn_readfirstlane(tx0);
+            const int c0 = kcs * (kRowBytes / (int)sizeof(T)) + (t & 3) * VEC;
+            const bool w1 = p.nsrc > 1 && c0 >= p.src[0].C;        // per lane: a chunk may straddle the two concat sources
+            const int cs = w1 ? c0 - p.src[0].C : c0;
+            const int Cs = w1 ? p.src[1].C : p.src[0].C;
+            const bool cok = cs < Cs;
+            load_affine<VEC>(p.src[w1], ns, cok ? cs : -1, pf.sc, pf.sh);
+            pf.mode = p.src[w1].mode;
+            pf.slope = pf.mode == MRISR_SRC_NORM ? LRELU_SLOPE : (pf.mode == MRISR_SRC_RELU ? 0.f : 1.f);
+            const char* b0 = image_base(p.src[0].ptr, ns, p.src[0].img_bytes);
+            const char* b1 = image_base(p.src[1].ptr, ns, p.src[1].img_bytes);
+            const char* base = w1 ? b1 : b0;
+            const unsigned Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W;
+            const int ys0 = ty0s - PAD - (w1 ? p.src[1].off_y : p.src[0].off_y);
+            const int xs0 = tx0s - PAD - (w1 ? p.src[1].off_x : p.src[0].off_x);
+            const unsigned C2 = Cs * (unsigned)sizeof(T), cbytes = (cok ? cs : 0) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < kMaxHaloIter; ++i) {
+                // (slots beyond the halo have hyx = -1: x = xs0 + 0xffff is out of range for every W < 32768)
+                const unsigned y = ys0 + (hyx[i] >> 16), x = xs0 + (hyx[i] & 0xffff);
+                const bool ok = cok & (y < Hs) & (x < Ws);
+                const unsigned off = mad_u24(mad_u24(y, Ws, x), C2, cbytes);
+                pf.h[i][0] = gload_vec16(reinterpret_cast<const T*>(base + (ok ? off : 0u)));
+                pf.ok[i] = ok;
+            }
+            return;
+        }
         if constexpr (pf_halo) {
             const int c0 = kc * (kRowBytes / (int)sizeof(T)) + (t & 3) * VEC;
             int which = 0, cs = c0;
-            if constexpr (NH == 1) {
-                if (p.nsrc > 1 && c0 >= p.src[0].C) { which = 1; cs = c0 - p.src[0].C; }
-            }
             if (cs >= p.src[which].C) cs = -1;
             load_affine<VEC>(p.src[which], n, cs, pf.sc, pf.sh);
             if constexpr (NH == 2) load_affine<VEC>(p.src[1], n, cs, pf.sc1, pf.sh1);
             pf.mode = p.src[which].mode;
             const T* base = (const T*)p.src[which].ptr;
             int mask = 0;
-            if constexpr (NH == 1) {
-                // branch-free: every slot loads (masked slots from element 0 of the tensor, a valid address) and the
-                // validity goes into a bit mask -> six back-to-back global_load_dwordx4, no exec juggling
-                pf.slope = pf.mode == MRISR_SRC_NORM ? LRELU_SLOPE : (pf.mode == MRISR_SRC_RELU ? 0.f : 1.f);
-                const int csafe = cs >= 0 ? cs : 0;
-#pragma unroll
-                for (int i = 0; i < kMaxHaloIter; ++i) {
-                    const int o = which ? geom.off1[i] : geom.off0[i];
-                    const bool ok = o >= 0 && cs >= 0;
-                    pf.h[i][0] = gload_vec16(base + (ok ? o : 0) + csafe);
-                    mask |= (ok ? 1 : 0) << i;
-                }
-            }
 #pragma unroll
             for (int i = 0; i < kMaxHaloIter; ++i) {
-                if constexpr (NH == 1) {
-                } else if constexpr (NH == 2) {
+                if constexpr (NH == 2) {
                     const int o0 = geom.off0[i], o1 = geom.off1[i];
                     if (o0 >= 0 && o1 >= 0 && cs >= 0) {
                         pf.h[i][0] = gload_vec16(base + o0 + cs);
@@ -272,29 +291,32 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
         }
         if constexpr (NH == 1) {
-            if (all_raw) {
-                // every source is stored as-is (input gradients, materialised activations, VGG): no arithmetic at all,
-                // the loaded vectors go to LDS with the padding slots zeroed
+            // straight-line: y = x*sc+sh, act = max(y, slope*y), unpredicated 16-B LDS
+            // store of every slot; the slots that must read as zero (conv padding, channels beyond Cin) are then
+            // overwritten by an exec-masked zero store - no per-element selects, and nothing at all inside the image
+            if (!all_raw) {   // (all sources stored as-is - input gradients, materialised activations, VGG: no arithmetic)
 #pragma unroll
                 for (int i = 0; i < kMaxHaloIter; ++i) {
-                    Vec16<T> v = pf.h[i][0];
-                    if (!((pf.mask >> i) & 1)) v.zero();
-                    *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
-                }
-            } else {
-                // straight-line: y = x*sc+sh, act = max(y, slope*y), masked slots -> 0, unpredicated 16-B LDS store
-#pragma unroll
-                for (int i = 0; i < kMaxHaloIter; ++i) {
-                    Vec16<T> v = pf.h[i][0];
+                    // (scalar fp32 ops on purpose: measured with the per-wave phase profile, v_pk_fma_f32 / v_pk_mul_f32 in
+                    // this loop run at half speed whenever the SIMD's other wave is in its MFMA block)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        const float y = fmaf(v.get(e), pf.sc[e], pf.sh[e]);
-                        v.set(e, fmaxf(y, pf.slope * y));
+                        const float y = fmaf(pf.h[i][0].get(e), pf.sc[e], pf.sh[e]);
+                        pf.h[i][0].set(e, fmaxf(y, pf.slope * y));
                     }
-                    if (!((pf.mask >> i) & 1)) v.zero();
-                    *reinterpret_cast<decltype(v.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = v.v;
                     if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots' temporaries live at a time
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < kMaxHaloIter; ++i)
+                *reinterpret_cast<decltype(pf.h[i][0].v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = pf.h[i][0].v;
+            Vec16<T> zv;
+            zv.zero();
+#pragma unroll
+            for (int i = 0; i < kMaxHaloIter; ++i) {
+                // (slots beyond the halo tile - only possible for i >= 4 - are never read: leave them alone)
+                const bool z = !pf.ok[i] && (i < 4 || hyx[i] >= 0);
+                if (z) *reinterpret_cast<decltype(zv.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = zv.v;
             }
         } else if constexpr (pf_halo) {
 #pragma unroll
@@ -359,18 +381,33 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // Straight-line per (pixel row mi, cout fragment ni): no per-quad branches (the bias comes from LDS, pixels
     // outside the image and channels >= Cout are handled by multiplying the statistics with 0/1 and by predicating
     // only the stores); bias / ReLU sit behind one block-uniform branch per fragment.
-    auto epilogue = [&](int n, int ty0, int tx0) {
+    auto epilogue = [&](int n_v, int ty0_v, int tx0_v) {
         if (p.dbg & 16) return;
-        T* outp = (T*)p.out;
-        int lh_e = lh;      // opaque copy: channel-dependent store addresses are recomputed per tile, not hoisted (and spilled)
+        // Addresses: scalar base of (image, tile origin, first channel of this cout block) - SALU after the
+        // readfirstlanes - plus one 32-bit per-lane byte offset per pixel row (two 24-bit mads) plus compile-time
+        // constants for the fragment / quad: no 64-bit per-lane arithmetic in front of the stores.
+        const int n = __builtin_amdgcn_readfirstlane(n_v), ty0 = __builtin_amdgcn_readfirstlane(ty0_v);
+        const int tx0 = __builtin_amdgcn_readfirstlane(tx0_v);
+        constexpr bool kPSE = EPI == MRISR_OUT_PIXEL_SHUFFLE2;
+        const int C4 = p.Cout >> 2;
+        // element offset of the tile origin: plain (n, ty0, tx0, bn0); pixel-shuffle (n, 2 ty0, 2 tx0, bn0 / 4)
+        const size_t e0 = kPSE ? ((size_t)(n * 2 * p.H + 2 * ty0) * (2 * p.W) + 2 * tx0) * C4 + (bn0 >> 2)
+                               : ((size_t)(n * p.H + ty0) * p.W + tx0) * p.Cout + bn0;
+        char* obase = (char*)p.out + e0 * sizeof(T);
+        const char* mbase = (const char*)p.mask + e0 * sizeof(T);     // (kEpiMask only)
+        int lh_e = lh;      // opaque copy: channel-dependent offsets are recomputed per tile, not hoisted (and spilled)
         asm volatile("" : "+v"(lh_e));
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int pl = wave * 64 + mi * 32 + lr;
-            const int oy = ty0 + (pl >> p.tw_log2), ox = tx0 + (pl & (TW - 1));
+            const int py = pl >> p.tw_log2, px = pl & (TW - 1);
+            const int oy = ty0 + py, ox = tx0 + px;
             const bool pv = oy < p.H && ox < p.W;
             const float pvf = pv ? 1.f : 0.f;
-            const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
+            // per-lane byte offset of this pixel relative to the tile origin (+ the lane's channel sub-offset)
+            const unsigned loff = kPSE ? mad_u24(mad_u24(2 * py, 2 * p.W, 2 * px), C4 * (unsigned)sizeof(T), 4 * lh_e * (unsigned)sizeof(T))
+                                       : mad_u24(mad_u24(py, p.W, px), p.Cout * (unsigned)sizeof(T),
+                                                 (sizeof(T) == 2 ? 8 : 4) * lh_e * (unsigned)sizeof(T));
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) {
                 if (has_br) {   // block-uniform: bias (from LDS) and ReLU applied in place on the accumulators
@@ -403,23 +440,24 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         packed[q] = cv.u;
                     } else if (pv && co < p.Cout && !(p.dbg & 1)) {
-                        if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2) {
+                        if constexpr (!kPSE) {
+                            const unsigned o = loff + (ni * 32 + 8 * q) * (unsigned)sizeof(T);
                             if constexpr (EPI == kEpiMask) {   // ReLU backward: keep the gradient where the activation is > 0
-                                const f32x4 m = gload<f32x4>((const float*)p.mask + pix * p.Cout + co);
+                                const f32x4 m = gload<f32x4>(mbase + o);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
                             }
-                            gstore(outp + pix * p.Cout + co, f32x4{v[0], v[1], v[2], v[3]});
-                        } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c')
-                            const int C4 = p.Cout >> 2, c4 = co >> 2;
+                            gstore(obase + o, f32x4{v[0], v[1], v[2], v[3]});
+                        } else {   // PixelShuffle(2): channel 4c'+2i+j -> (2y+i, 2x+j, c'); this lane: c' = (ni*32 + 8q)/4 + lh
+                            const unsigned o = mad_u24(mad_u24(2 * py, 2 * p.W, 2 * px), C4 * (unsigned)sizeof(T),
+                                                       (ni * 8 + 2 * q + lh_e) * (unsigned)sizeof(T));
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                gstore(outp + ((size_t)(n * 2 * p.H + 2 * oy + (j >> 1)) * (2 * p.W) + 2 * ox + (j & 1)) * C4 + c4,
-                                       from_f32<T>(v[j]));
+                                gstore(obase + o + ((size_t)(j >> 1) * (2 * p.W) + (j & 1)) * C4 * sizeof(T), from_f32<T>(v[j]));
                         }
                     }
                 }
-                if constexpr (EPI != MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
+                if constexpr (!kPSE && sizeof(T) == 2) {
                     // lanes l and l+32 hold the two 4-channel halves of each 8-channel group of the same pixel:
                     // exchange so that every lane owns 8 consecutive channels -> 16-byte stores (half the store
                     // instructions).  Quad pair (q, q+1): low half keeps group q, high half keeps group q+1.
@@ -430,9 +468,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                         u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
                         const int co8 = bn0 + ni * 32 + 8 * (q + lh_e);      // first of the 8 channels this lane now owns
+                        const unsigned ob = loff + (ni * 32 + 8 * q) * (unsigned)sizeof(T);
                         if (pv && co8 < p.Cout && !(p.dbg & 1)) {
                             if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
-                                const u32x4 m = gload<u32x4>((const T*)p.mask + pix * p.Cout + co8);
+                                const u32x4 m = gload<u32x4>(mbase + ob);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const unsigned lo = __uint_as_float(m[k] << 16) > 0.f ? 0x0000ffffu : 0u;
@@ -440,16 +479,16 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                                     o[k] &= (lo | hi);
                                 }
                             }
-                            gstore(outp + pix * p.Cout + co8, o);
+                            gstore(obase + ob, o);
                         }
                     }
                 }
-                if constexpr (EPI == MRISR_OUT_PIXEL_SHUFFLE2 && sizeof(T) == 2) {
+                if constexpr (kPSE && sizeof(T) == 2) {
                     // PixelShuffle(2): conv channel 4c'+2i+j -> pixel (2y+i, 2x+j), channel c'.  packed[q] = the four
                     // (i,j) values of c' = cb + 2q + lh_e.  For one (i,j): this lane holds c' = cb + {0,2,4,6} + lh_e; one
                     // permlane32 swap + a 16-bit interleave give the low half c' = cb..cb+3 and the high half
                     // cb+4..cb+7 -> one 8-byte store per (i,j) instead of four 2-byte stores.
-                    const int C4 = p.Cout >> 2, cb = (bn0 + ni * 32) >> 2;
+                    const int cb = (bn0 + ni * 32) >> 2;
                     const bool okc = cb + 4 * lh_e < C4;                 // (C4 % 4 == 0: host-checked for this epilogue)
 #pragma unroll
                     for (int ij = 0; ij < 4; ++ij) {
@@ -462,8 +501,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         auto r = __builtin_amdgcn_permlane32_swap(P0, P1, false, false);   // P0.hi-lanes <-> P1.lo-lanes
                         const unsigned X = r[0], Y = r[1];   // low half: X={0,2} Y={1,3}; high half: X={4,6} Y={5,7}
                         const u32x2 o = {(X & 0xffffu) | (Y << 16), (X >> 16) | (Y & 0xffff0000u)};
-                        if (pv && okc && !(p.dbg & 1))
-                            gstore(outp + ((size_t)(n * 2 * p.H + 2 * oy + (ij >> 1)) * (2 * p.W) + 2 * ox + (ij & 1)) * C4 + cb + 4 * lh_e, o);
+                        // scalar: sub-pixel (i, j) and the fragment's first c'
+                        char* ob = obase + (((size_t)(ij >> 1) * (2 * p.W) + (ij & 1)) * C4 + ni * 8) * sizeof(T);
+                        if (pv && okc && !(p.dbg & 1)) gstore(ob + loff, o);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // bound the scheduling window: one (mi, ni) group's temporaries live at a time
@@ -479,7 +519,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         decode(cur_tile, cur_n, cur_ty0, cur_tx0);
         set_geom(cur_n, cur_ty0, cur_tx0);
         issue_weights(0);
-        issue(cur_n, 0);
+        issue(cur_n, 0, cur_ty0, cur_tx0);
     }
     PT_DECL
     for (int tick = 0; tick < nticks; ++tick) {
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     }
                 }
                 PT_MARK(2)
-                issue(nxt_n, nxt_kc);     // unconditional: after the last item this re-loads valid addresses and is never committed
+                issue(nxt_n, nxt_kc, nxt_ty0, nxt_tx0);     // unconditional: after the last item this re-loads valid addresses and is never committed
                 PT_MARK(3)
             }
             if (ep_pending) {
@@ -558,17 +598,22 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
 #endif
     }
 #ifdef MRISR_PHASE_TIMING
-    if (blockIdx.x == gridDim.x / 2 && (t == 0)) {
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {   // accumulated over launches (mrisr_debug_phase_reset clears)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) g_phase_cycles[half][k] = pt_acc[k];
+        for (int k = 0; k < 12; ++k) atomicAdd(&g_phase_cycles[threadIdx.x >> 6][k], pt_acc[k]);
+        if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[0][11], 1ull);   // launches
     }
 #endif
 }
 
 #ifndef MRISR_KERNEL_ONLY   // (tuning: a translation unit that instantiates single kernels includes this file with it set)
 #ifdef MRISR_PHASE_TIMING
-extern "C" int mrisr_debug_phase_cycles(unsigned long long* out24) {
-    return (int)hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 24);
+extern "C" int mrisr_debug_phase_reset() {
+    static unsigned long long zeros[96];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zeros, sizeof(zeros));
+}
+extern "C" int mrisr_debug_phase_cycles(unsigned long long* out96) {
+    return (int)hipMemcpyFromSymbol(out96, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 96);
 }
 #endif
 // ------------------------------------------------------------------------------------------------
@@ -705,7 +750,11 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
         if (a.spatial == MRISR_SP_POOL2 && (vh != d->H || vw != d->W || a.off_y || a.off_x))
             MRISR_FAIL(MRISR_E_SHAPE, "%s: pooled src%d %dx%d != conv input %dx%d", who, s, vh, vw, d->H, d->W);
         if ((size_t)d->N * a.H * a.W * a.C >= (1ull << 31)) MRISR_FAIL(MRISR_E_SHAPE, "%s: src%d exceeds 2^31 elements", who, s);
-        p.src[s] = SrcDev{a.ptr, a.scale, a.shift, a.C, a.H, a.W, a.mode, a.off_y, a.off_x};
+        // ranges of the 24-bit / 32-bit offset arithmetic of the plain loader
+        const size_t esz = d->dtype == MRISR_BF16 ? 2 : 4;
+        if ((size_t)a.H * a.W >= (1u << 24) || a.W >= 32768 || (size_t)a.C * esz >= (1u << 24) || (size_t)a.H * a.W * a.C * esz >= (1ull << 32))
+            MRISR_FAIL(MRISR_E_SHAPE, "%s: src%d image %dx%dx%d exceeds the loader's offset range", who, s, a.H, a.W, a.C);
+        p.src[s] = SrcDev{a.ptr, a.scale, a.shift, a.C, a.H, a.W, a.mode, a.off_y, a.off_x, (unsigned)((size_t)a.H * a.W * a.C * esz)};
         csum += a.C;
     }
     if (d->combine == MRISR_COMBINE_BLEND) {

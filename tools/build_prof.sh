@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 python -m mri_superresolution_amd.build
 mkdir -p build/prof
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DMRISR_PHASE_TIMING \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DMRISR_PHASE_TIMING -fno-slp-vectorize \
     -c mri_superresolution_amd/csrc/conv_fwd.hip -o build/prof/conv_fwd.o
 objs=$(ls build/mrisr/*.o | grep -v conv_fwd.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o mri_superresolution_amd/libmrisr_prof.so build/prof/conv_fwd.o $objs

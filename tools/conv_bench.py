@@ -112,6 +112,8 @@ def main():
             fn = calls[kind]
             fn()
             torch.cuda.synchronize()
+            if hasattr(L.load(), "mrisr_debug_phase_reset"):
+                L.load().mrisr_debug_phase_reset()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
@@ -125,12 +127,12 @@ def main():
                 # profiling build (tools/build_prof.sh, MRISR_LIB=...): s_memtime cycles of the middle workgroup's
                 # two halves in the last launch: load wait, commit, issue, epilogue, barrier (vector side), MFMA block,
                 # barrier (matrix side), loop overhead
-                buf = (C.c_ulonglong * 24)()
+                buf = (C.c_ulonglong * 96)()
                 L.load().mrisr_debug_phase_cycles(buf)
                 names = ["ldwait", "commit", "geom", "issue", "epilog", "bar_v", "mfma", "bar_m", "loop", "flush", "-", "-"]
-                for h in range(2):
-                    v = [buf[12 * h + k] for k in range(10)]
-                    line += f"\n      half{h} cycles total {sum(v):8d}: " + " ".join(f"{n}={x}" for n, x in zip(names, v))
+                for h in range(8):
+                    v = [buf[12 * h + k] // max(a.iters, 1) for k in range(10)]
+                    line += f"\n      wave{h} cycles total {sum(v):8d}: " + " ".join(f"{n}={x}" for n, x in zip(names, v))
         print(line, flush=True)
     print("total us per kind:", {k: round(v, 1) for k, v in tot.items()})
 
