@@ -521,6 +521,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         issue_weights(0);
         issue(cur_n, 0, cur_ty0, cur_tx0);
     }
+    // static priority for the younger half (waves 4-7 lose the VALU arbitration to the older half of their SIMD on every
+    // tick: measured 26 k vs 31 k cycles for the same commit work); a provably uniform condition, s_setprio ignores EXEC
+#ifndef MRISR_NO_STATIC_PRIO
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
     PT_DECL
     for (int tick = 0; tick < nticks; ++tick) {
         const int phase = tick - half;
