@@ -66,7 +66,7 @@ constexpr int kEpiMask = 2;         // template-only epilogue kind: plain store 
 // libmrisr.so.
 #ifdef MRISR_PHASE_TIMING
 __device__ unsigned long long g_phase_cycles[8][12];
-#define PT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime();
+#define PT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime(); const unsigned long long pt_r0 = __builtin_amdgcn_s_memrealtime();
 #define PT_MARK(k) { const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t; pt_t = pt_now; }
 #define PT_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0f70)   /* vmcnt(0) only (gfx9 encoding: lgkmcnt 15, expcnt 7) */
 #else
@@ -95,7 +95,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     const int npix_halo = hw * hh;
     constexpr int halo_bytes = kMaxHaloIter * 64 * kHaloRowBytes;   // full slots: commits are unpredicated
     char* lds_halo = smem + half * halo_bytes;
-    char* lds_w = smem + 2 * halo_bytes + (WS ? 0 : half * (WIMG_VECS * 16));
+    // streamed weights: TWO images shared by both halves - item c (the halves run the same (tile, chunk) sequence one
+    // tick apart) uses image c & 1; each half loads and writes the image of every other item (see the schedule below)
+    char* lds_w = smem + 2 * halo_bytes;
     float* lds_bias = reinterpret_cast<float*>(smem + 2 * halo_bytes + (WS ? p.nchunks : 2) * (WIMG_VECS * 16));   // [BN]
 
     // this workgroup: one cout block, tiles [bt0, bt1); this half: [tile0, tile1)
@@ -117,6 +119,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // leave room: BN = 32); otherwise the halo is staged synchronously in the vector phase
     constexpr int NH = SPATIAL == MRISR_SP_NONE ? 1 : SPATIAL == kLoaderBlend ? 2 : (BN == 32 ? 4 : 0);
     constexpr bool pf_halo = NH > 0;
+    // halo slots the plain loader touches: a 1x1 conv has no halo ring, its 256 pixels fill 4 slots exactly
+    constexpr int NSLOT = KS == 1 ? 4 : kMaxHaloIter;
 
     float blend_a = 0.f;
     if (p.combine == MRISR_COMBINE_BLEND) blend_a = 1.f / (1.f + __expf(-gload<float>(p.blend_alpha)));
@@ -194,13 +198,24 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // streamed weights (not weights-stationary): the next chunk's image, issued at the start of the matrix phase
     // (L2-resident, and keeping these 36 VGPRs dead during the epilogue avoids spills)
     auto issue_weights = [&](int kc) {
-        if (p.dbg & 4) return;
+        if (p.dbg & (4 | 256)) return;     // (ablation: 256 = no weight loads)
         if constexpr (!WS) {
             const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase + (size_t)kc * (WIMG_VECS * 16));
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int v = t + j * kConvThreads;
                 if (v < WIMG_VECS) pf.w[j].v = gload<decltype(pf.w[j].v)>(wsrc + v);
+            }
+        }
+    };
+    auto store_weights = [&](int item) {     // prefetched image -> LDS image (item & 1)
+        if (p.dbg & 128) return;             // (ablation: 128 = no weight LDS stores)
+        if constexpr (!WS) {
+            char* dst = lds_w + (size_t)(item & 1) * (WIMG_VECS * 16);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int v = t + j * kConvThreads;
+                if (v < WIMG_VECS) *reinterpret_cast<decltype(pf.w[j].v)*>(dst + (size_t)v * 16) = pf.w[j].v;
             }
         }
     };
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             const int xs0 = tx0s - PAD - (w1 ? p.src[1].off_x : p.src[0].off_x);
             const unsigned C2 = Cs * (unsigned)sizeof(T), cbytes = (cok ? cs : 0) * (unsigned)sizeof(T);
 #pragma unroll
-            for (int i = 0; i < kMaxHaloIter; ++i) {
+            for (int i = 0; i < NSLOT; ++i) {
                 // (slots beyond the halo have hyx = -1: x = xs0 + 0xffff is out of range for every W < 32768)
                 const unsigned y = ys0 + (hyx[i] >> 16), x = xs0 + (hyx[i] & 0xffff);
                 const bool ok = cok & (y < Hs) & (x < Ws);
@@ -283,20 +298,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // transform + store the prefetched item into LDS (gather modes: stage synchronously)
     auto commit = [&](int n, int kc, int ty0, int tx0) {
         if (p.dbg & 2) return;
-        if constexpr (!WS) {
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int v = t + j * kConvThreads;
-                if (v < WIMG_VECS) *reinterpret_cast<decltype(pf.w[j].v)*>(lds_w + (size_t)v * 16) = pf.w[j].v;
-            }
-        }
         if constexpr (NH == 1) {
             // straight-line: y = x*sc+sh, act = max(y, slope*y), unpredicated 16-B LDS
             // store of every slot; the slots that must read as zero (conv padding, channels beyond Cin) are then
             // overwritten by an exec-masked zero store - no per-element selects, and nothing at all inside the image
             if (!all_raw) {   // (all sources stored as-is - input gradients, materialised activations, VGG: no arithmetic)
 #pragma unroll
-                for (int i = 0; i < kMaxHaloIter; ++i) {
+                for (int i = 0; i < NSLOT; ++i) {
                     // (scalar fp32 ops on purpose: measured with the per-wave phase profile, v_pk_fma_f32 / v_pk_mul_f32 in
                     // this loop run at half speed whenever the SIMD's other wave is in its MFMA block)
 #pragma unroll
@@ -308,12 +316,12 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 }
             }
 #pragma unroll
-            for (int i = 0; i < kMaxHaloIter; ++i)
+            for (int i = 0; i < NSLOT; ++i)
                 *reinterpret_cast<decltype(pf.h[i][0].v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = pf.h[i][0].v;
             Vec16<T> zv;
             zv.zero();
 #pragma unroll
-            for (int i = 0; i < kMaxHaloIter; ++i) {
+            for (int i = 0; i < NSLOT; ++i) {
                 // (slots beyond the halo tile - only possible for i >= 4 - are never read: leave them alone)
                 const bool z = !pf.ok[i] && (i < 4 || hyx[i] >= 0);
                 if (z) *reinterpret_cast<decltype(zv.v)*>(lds_halo + halo_off((t >> 2) + 64 * i, t & 3)) = zv.v;
@@ -515,11 +523,21 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     int nxt_tile = tile0, nxt_kc = 0, nxt_n = 0, nxt_ty0 = 0, nxt_tx0 = 0;       // item c + 1
     int ep_n = 0, ep_ty0 = 0, ep_tx0 = 0;
     bool ep_pending = false;
+    // Streamed weights, shared between the halves: half 0 writes the image of the even items (at its own commit of that
+    // item), half 1 the image of the odd items (one item ahead, at its commit of the even item before): an image is
+    // written in a tick in which nobody reads it (item c: half 0 reads in tick 2c+1, half 1 in tick 2c+2; image c & 1 is
+    // rewritten for item c+2 in tick 2c+3 or 2c+4), and every half loads / stores 9 vectors per thread for every OTHER
+    // item instead of for every item (measured: the 9 weight ds_write_b128 were half of the commit time).  The duty runs
+    // on half 0's item count, so half 1 keeps serving half 0's last tile when it has one tile less.
+    const int nitems0 = nh0 * p.nchunks;
+    int wkc = half;            // cin chunk of this half's next weight target (items half, half + 2, ...; nchunks >= 3 here)
     if (nitems > 0) {
         decode(cur_tile, cur_n, cur_ty0, cur_tx0);
         set_geom(cur_n, cur_ty0, cur_tx0);
-        issue_weights(0);
         issue(cur_n, 0, cur_ty0, cur_tx0);
+    }
+    if constexpr (!WS) {
+        if (half < nitems0) issue_weights(wkc);
     }
     // static priority for the younger half (waves 4-7 lose the VALU arbitration to the older half of their SIMD on every
     // tick: measured 26 k vs 31 k cycles for the same commit work); a provably uniform condition, s_setprio ignores EXEC
@@ -533,6 +551,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         PT_MARK(8)
         if (phase >= 0 && (phase & 1) == 0) {
             // ------------------------------------------------ vector phase
+            if constexpr (!WS) {
+                if (!(c & 1) && c + half < nitems0) store_weights(c + half);
+            }
             // Order: commit item c (its loads were issued one full tick pair ago) -> issue the loads of item c+1
             // right away (the prefetch registers are free again) -> only then the epilogue of the tile that finished
             // in the previous matrix phase.  The loads thus have the rest of this phase plus the whole matrix phase
@@ -563,13 +584,57 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 ep_pending = false;
                 PT_MARK(9)
             }
-        } else if (phase >= 0 && c < nitems) {
-            // ------------------------------------------------ matrix phase
-            issue_weights(nxt_kc);    // unconditional (a redundant load after the last item): keeps the registers dead between commit and here
-            const char* wl = lds_w + (WS ? (size_t)cur_kc * (WIMG_VECS * 16) : 0);
+        } else if (phase >= 0) {
+          // ------------------------------------------------ matrix phase
+          if constexpr (!WS) {
+              // odd item index: load the image this half stores in its next vector phase (target item c + 1 + half)
+              if ((c & 1) && c + 1 + half < nitems0) {
+                  wkc += 2;
+                  if (wkc >= p.nchunks) wkc -= p.nchunks;
+                  issue_weights(wkc);
+              } else {
+                  // not loaded on this path: an empty asm "defines" the registers so that they are not live across the
+                  // rest of the loop (36 VGPRs)
+#pragma unroll
+                  for (int j = 0; j < NW; ++j) asm volatile("" : "=v"(pf.w[j].v));
+              }
+          }
+          if (c < nitems) {
+            const char* wl = lds_w + (size_t)(WS ? cur_kc : (c & 1)) * (WIMG_VECS * 16);
             // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
             // out of the persistent loop into 36 VGPRs
             asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
+#ifdef MRISR_PIPE_MMA   // experiment (tools/build_variant.sh pipe -DMRISR_PIPE_MMA): fragment reads one step ahead, order pinned
+            if (!(p.dbg & 8)) {
+                constexpr int NSTEP = 2 * NTAPS;
+                frag_t xf[2][2], wf[2][NF];
+                auto load_step = [&](int st, int buf) {
+                    const int tap = st >> 1, ks = st & 1;
+                    const int tapoff = ((tap / KS) * hw + (tap % KS)) * kHaloRowBytes;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        xf[buf][mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+                        wf[buf][ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
+                };
+                load_step(0, 0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    if (st + 1 < NSTEP) load_step(st + 1, (st + 1) & 1);
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mma<T>::run(wf[st & 1][ni], xf[st & 1][mi], acc[ni][mi]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + NF, 0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NF, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
+                }
+            }
+#else
             if (!(p.dbg & 8)) {
 #pragma unroll
                 for (int tap = 0; tap < NTAPS; ++tap) {
@@ -590,11 +655,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     }
                 }
             }
+#endif
             if (cur_kc == p.nchunks - 1) {
                 ep_pending = true;
                 ep_n = cur_n; ep_ty0 = cur_ty0; ep_tx0 = cur_tx0;
             }
             cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
+          }
             PT_MARK(6)
         }
         if (!(p.dbg & 64)) __syncthreads();
@@ -604,6 +671,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     }
 #ifdef MRISR_PHASE_TIMING
     if (blockIdx.x == gridDim.x / 2 && lane == 0) {   // accumulated over launches (mrisr_debug_phase_reset clears)
+        pt_acc[10] = __builtin_amdgcn_s_memrealtime() - pt_r0;     // 100 MHz ticks of the same interval -> shader clock
 #pragma unroll
         for (int k = 0; k < 12; ++k) atomicAdd(&g_phase_cycles[threadIdx.x >> 6][k], pt_acc[k]);
         if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[0][11], 1ull);   // launches

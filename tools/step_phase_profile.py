@@ -54,7 +54,8 @@ def main():
     for w in range(8):
         v = [buf[12 * w + k] for k in range(10)]
         tot = sum(v)
-        print(f"wave{w}: total {tot / launches:9.0f} cycles/launch  " + " ".join(f"{n}={100.0 * x / tot:4.1f}%" for n, x in zip(names, v)))
+        rt = buf[12 * w + 10]
+        print(f"wave{w}: total {tot / launches:9.0f} cycles/launch, {rt / 100.0 / launches:6.1f} us/launch -> shader clock {tot / (rt / 100.0) / 1e3:5.3f} GHz  " + " ".join(f"{n}={100.0 * x / tot:4.1f}%" for n, x in zip(names, v)))
 
 
 if __name__ == "__main__":
