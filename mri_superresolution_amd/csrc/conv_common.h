@@ -25,7 +25,7 @@ __device__ __forceinline__ int halo_off(int row, int chunk) { return row * kHalo
 // need no bounds predicate) + the weight images + BN floats of bias
 static inline size_t conv_halo_bytes() { return (size_t)kMaxHaloIter * 64 * kHaloRowBytes; }
 static inline bool conv_weights_stationary(int nchunks, size_t wimg) {
-    return nchunks * wimg + 2 * conv_halo_bytes() + 64 * sizeof(float) <= 158 * 1024;
+    return nchunks * wimg + 2 * conv_halo_bytes() + (64 + 128) * sizeof(float) <= 158 * 1024;   // + bias, affine tables
 }
 // wgrad kernel variant: 0 = generic, 1 / 2 / 4 = FAST with that k-step interleave (bf16 3x3 plain loader, 8x32 tiles,
 // every channel block of the launch holding the same number of 32x32 fragment pairs)

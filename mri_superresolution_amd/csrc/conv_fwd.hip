@@ -48,6 +48,7 @@ struct Prefetch {
     float sc1[NH == 2 ? Vec16<T>::N : 1], sh1[NH == 2 ? Vec16<T>::N : 1];   // blend: source 1
     int mask, mode;
     bool ok[kMaxHaloIter];                        // NH == 1: slot holds an in-image pixel of an existing channel (else: zero)
+    float aff;                                    // NH == 1, first wave of the half: one entry of the chunk's affine table
     float slope;                                  // NH == 1: activation as max(y, slope*y): 0.2 NORM, 1 RAW, 0 RELU
 };
 
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // tick apart) uses image c & 1; each half loads and writes the image of every other item (see the schedule below)
     char* lds_w = smem + 2 * halo_bytes;
     float* lds_bias = reinterpret_cast<float*>(smem + 2 * halo_bytes + (WS ? p.nchunks : 2) * (WIMG_VECS * 16));   // [BN]
+    // plain loader: GroupNorm scale (entries 0..31) / shift (32..63) of the cin chunk this half commits next
+    float* lds_aff = lds_bias + BN + half * 64;
 
     // this workgroup: one cout block, tiles [bt0, bt1); this half: [tile0, tile1)
     const int cb = blockIdx.x % p.ncb;
@@ -234,8 +237,26 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             const int cs = w1 ? c0 - p.src[0].C : c0;
             const int Cs = w1 ? p.src[1].C : p.src[0].C;
             const bool cok = cs < Cs;
-            load_affine<VEC>(p.src[w1], ns, cok ? cs : -1, pf.sc, pf.sh);
-            pf.mode = p.src[w1].mode;
+            if (wave == 0) {
+                // the chunk's per-channel affine: ONE dword per lane of the half's first wave (lanes 0-31 scale, 32-63
+                // shift of channel kc*BK + lane%32) instead of four 16-byte loads in every thread; it goes to an LDS
+                // table at the end of the next matrix phase and is read back by the commit after that
+                constexpr int BKE = kRowBytes / (int)sizeof(T);
+                const int j = lane & 31, ch = kcs * BKE + j;
+                const bool wj = p.nsrc > 1 && ch >= p.src[0].C;
+                const int cj = wj ? ch - p.src[0].C : ch;
+                // (opaque local copies: a select between two fields of `p` is otherwise folded into a dynamically indexed
+                // load of the struct, which then lives in scratch memory)
+                const float *s0p = p.src[0].scale, *s1p = p.src[1].scale, *h0p = p.src[0].shift, *h1p = p.src[1].shift;
+                int C0j = p.src[0].C, C1j = p.src[1].C, m0j = p.src[0].mode, m1j = p.src[1].mode;
+                asm volatile("" : "+s"(s0p), "+s"(s1p), "+s"(h0p), "+s"(h1p), "+s"(C0j), "+s"(C1j), "+s"(m0j), "+s"(m1j));
+                const int Cj = wj ? C1j : C0j, mj = wj ? m1j : m0j;
+                const float* tj = lane < 32 ? (wj ? s1p : s0p) : (wj ? h1p : h0p);
+                float v = lane < 32 ? 1.f : 0.f;
+                if (j < BKE && mj == MRISR_SRC_NORM && cj < Cj) v = gload<float>(tj + (size_t)ns * Cj + cj);
+                pf.aff = v;
+            }
+            pf.mode = w1 ? p.src[1].mode : p.src[0].mode;
             pf.slope = pf.mode == MRISR_SRC_NORM ? LRELU_SLOPE : (pf.mode == MRISR_SRC_RELU ? 0.f : 1.f);
             const char* b0 = image_base(p.src[0].ptr, ns, p.src[0].img_bytes);
             const char* b1 = image_base(p.src[1].ptr, ns, p.src[1].img_bytes);
@@ -303,13 +324,21 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             // store of every slot; the slots that must read as zero (conv padding, channels beyond Cin) are then
             // overwritten by an exec-masked zero store - no per-element selects, and nothing at all inside the image
             if (!all_raw) {   // (all sources stored as-is - input gradients, materialised activations, VGG: no arithmetic)
+                float sc[VEC], sh[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(lds_aff + (t & 3) * VEC + e);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_aff + 32 + (t & 3) * VEC + e);
+                    sc[e] = a4[0]; sc[e + 1] = a4[1]; sc[e + 2] = a4[2]; sc[e + 3] = a4[3];
+                    sh[e] = b4[0]; sh[e + 1] = b4[1]; sh[e + 2] = b4[2]; sh[e + 3] = b4[3];
+                }
 #pragma unroll
                 for (int i = 0; i < NSLOT; ++i) {
                     // (scalar fp32 ops on purpose: measured with the per-wave phase profile, v_pk_fma_f32 / v_pk_mul_f32 in
                     // this loop run at half speed whenever the SIMD's other wave is in its MFMA block)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        const float y = fmaf(pf.h[i][0].get(e), pf.sc[e], pf.sh[e]);
+                        const float y = fmaf(pf.h[i][0].get(e), sc[e], sh[e]);
                         pf.h[i][0].set(e, fmaxf(y, pf.slope * y));
                     }
                     if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots' temporaries live at a time
@@ -539,6 +568,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     if constexpr (!WS) {
         if (half < nitems0) issue_weights(wkc);
     }
+    if constexpr (NH == 1) {
+        if (wave == 0 && nitems > 0) lds_aff[lane] = pf.aff;     // first item's table; later ones at the end of a matrix phase
+        __syncthreads();
+    }
     // static priority for the younger half (waves 4-7 lose the VALU arbitration to the older half of their SIMD on every
     // tick: measured 26 k vs 31 k cycles for the same commit work); a provably uniform condition, s_setprio ignores EXEC
 #ifndef MRISR_NO_STATIC_PRIO
@@ -604,8 +637,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
             // out of the persistent loop into 36 VGPRs
             asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
-#ifdef MRISR_PIPE_MMA   // experiment (tools/build_variant.sh pipe -DMRISR_PIPE_MMA): fragment reads one step ahead, order pinned
+#ifndef MRISR_NO_PIPE_MMA
             if (!(p.dbg & 8)) {
+                // 2 * NTAPS steps of (2 pixel fragments, NF weight fragments, 2 * NF MFMAs), software-pipelined by one step
+                // with two fragment sets: the LDS reads of step s+1 are issued before the MFMAs of step s; the order is
+                // pinned with sched_group_barrier (hipcc otherwise sinks the reads back next to their use and waits for
+                // them at every tap).  Alone the block takes 2.8 k instead of 3.9 k cycles (ideal 72 x 37 = 2.7 k); it
+                // paid in the training step (+1.3 %, A/B on one box) only once the vector phase had been trimmed.
                 constexpr int NSTEP = 2 * NTAPS;
                 frag_t xf[2][2], wf[2][NF];
                 auto load_step = [&](int st, int buf) {
@@ -661,6 +699,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 ep_n = cur_n; ep_ty0 = cur_ty0; ep_tx0 = cur_tx0;
             }
             cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
+            if constexpr (NH == 1) {
+                // affine table of the item this half commits in the next tick (loaded by its last issue)
+                if (wave == 0) lds_aff[lane] = pf.aff;
+            }
           }
             PT_MARK(6)
         }
@@ -870,7 +912,7 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
     const size_t wimg = (size_t)KS * KS * BN * kRowBytes;
     // weights-stationary when every cin chunk fits next to the two halo tiles
     p.ws = conv_weights_stationary(p.nchunks, wimg) ? 1 : 0;
-    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg + BN * sizeof(float);
+    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg + (BN + 128) * sizeof(float);
     p.ntiles = p.N * p.tiles_y * p.tiles_x;
     int per_cb = num_cus() / p.ncb;                     // persistent workgroups per cout block, one per CU
     if (per_cb < 1) per_cb = 1;
