@@ -51,7 +51,9 @@ extern "C" {
 /* GroupNorm statistics buffers are [MRISR_STAT_SLOTS][N][groups][2] doubles (sum, sum of squares): producers
  * spread their atomics over the slots (same-address fp64 atomics serialise at ~170 ns each on gfx950),
  * mrisr_gn_finalize adds the slots up.  Zero the whole buffer before use.                                  */
+#ifndef MRISR_STAT_SLOTS
 #define MRISR_STAT_SLOTS 16
+#endif
 #define MRISR_OUT_PLAIN 0
 #define MRISR_OUT_PIXEL_SHUFFLE2 1 /* out[n,2y+i,2x+j,c/4] = conv[n,y,x,c], c=4c'+2i+j (unet_model.py:102) */
 

@@ -13,7 +13,7 @@ SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
 SP_NONE, SP_POOL2, SP_UP2 = 0, 1, 2
 COMBINE_CONCAT, COMBINE_BLEND = 0, 1
 OUT_PLAIN, OUT_PIXEL_SHUFFLE2 = 0, 1
-STAT_SLOTS = 16            # MRISR_STAT_SLOTS
+STAT_SLOTS = int(os.environ.get("MRISR_STAT_SLOTS", "16"))   # MRISR_STAT_SLOTS (env: tuning builds compiled with another value)
 
 _vp, _fp, _dp, _i, _f, _d, _sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 

@@ -134,5 +134,10 @@ __device__ __forceinline__ void up2_coord(int dst, int in_size, int& i0, int& i1
 __device__ __forceinline__ size_t stat_slot_off(int N, int groups) {
     return (size_t)((blockIdx.x + blockIdx.y) & (MRISR_STAT_SLOTS - 1)) * N * groups * 2;
 }
+// same, from a logical workgroup index (kernels that re-order their workgroups: neighbours in the LOGICAL order work on
+// the same image at the same time and must not share a slot)
+__device__ __forceinline__ size_t stat_slot_off_id(int id, int N, int groups) {
+    return (size_t)(id & (MRISR_STAT_SLOTS - 1)) * N * groups * 2;
+}
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

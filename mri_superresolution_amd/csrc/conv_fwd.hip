@@ -104,16 +104,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     float* lds_aff = lds_bias + BN + half * 64;
 
     // this workgroup: one cout block, tiles [bt0, bt1); this half: [tile0, tile1)
-    // XCD-aware order (weights-stationary variants): workgroup b runs on XCD b % 8, so the logical index
-    // (b % 8) * (grid / 8) + b / 8 puts CONSECUTIVE logical workgroups - the ncb cout blocks of the same tiles, then the
-    // neighbouring tiles - on one XCD, i.e. behind one L2: an input tile is fetched into that L2 once instead of once per
-    // cout block, and neighbouring tiles share their halo rows there.  Measured per kernel inside the training step (A/B
-    // on one box): 64-channel layers 138 -> 129 us, the pixel-shuffle conv (2 cout blocks) 314 -> 238 us.  The
-    // streamed-weights variant keeps the plain order: there b % ncb pins ONE cout block's weight images (re-streamed
-    // for every tile, 9x the activation traffic) to each XCD's L2, and the remap cost it 9 % (100 -> 109.5 us).
+    // XCD-aware order: workgroup b runs on XCD b % 8, so the logical index (b % 8) * (grid / 8) + b / 8 puts CONSECUTIVE
+    // logical workgroups - the ncb cout blocks of the same tiles, then the neighbouring tiles - on one XCD, i.e. behind
+    // one L2: an input tile is fetched into that L2 once instead of once per cout block, and neighbouring tiles share
+    // their halo rows there.  The GroupNorm statistics slot must then come from the LOGICAL index too: the workgroups of
+    // one XCD work on the same image, and with the slot taken from blockIdx (= XCD + 8 k) they shared 2 of the 16 slots
+    // - same-address fp64 atomics that cost the forward convs 10-30 % until the slot followed the logical order.
+    // Measured per kernel inside the training step (A/B on one box): 64-channel layers 138 -> 121 us, the pixel-shuffle
+    // conv (2 cout blocks) 314 -> 218 us, streamed-weights layers 103 -> 101.5 us; step +2.3 %.
     int bid = blockIdx.x;
 #ifndef MRISR_NO_XCD_REMAP
-    if (WS && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
 #endif
     const int cb = bid % p.ncb;
     const int bt0 = (bid / p.ncb) * p.tiles_per_block;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 const float s = half_wave_sum(st_s[ni][q]), ss = half_wave_sum(st_ss[ni][q]);
                 if (lr == 0 && co < p.Cout) {
                     const int g = co / gs;
-                    double* sp = p.stats + stat_slot_off(p.N, p.groups) + ((size_t)n * p.groups + g) * 2;
+                    double* sp = p.stats + stat_slot_off_id(bid, p.N, p.groups) + ((size_t)n * p.groups + g) * 2;
                     atomic_add_f64(sp, (double)s);
                     atomic_add_f64(sp + 1, (double)ss);
                 }

@@ -65,7 +65,21 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     const int buf_bytes = 256 * 128 + npix_halo * 128;       // [dy 256 px][halo px], 128-B rows
 
     const int ncib = (p.Cin + BC - 1) / BC;
-    const int cib = blockIdx.x % ncib, cob = blockIdx.x / ncib;
+    // XCD-aware order (as in the forward kernel's weights-stationary variants): workgroups are dispatched x-fastest and
+    // land on XCD (linear id) % 8; the logical index (id % 8) * (G / 8) + id / 8 puts the channel-block pairs of one
+    // k-slice - which all read the same dy / activation tiles - and the neighbouring slices behind one L2
+    int bx = blockIdx.x, by = blockIdx.y;
+#ifndef MRISR_NO_XCD_REMAP
+    {
+        const int G = gridDim.x * gridDim.y;
+        if ((G & 7) == 0) {
+            const int id = by * gridDim.x + bx, lid = (id & 7) * (G >> 3) + (id >> 3);
+            by = lid / gridDim.x;
+            bx = lid - by * gridDim.x;
+        }
+    }
+#endif
+    const int cib = bx % ncib, cob = bx / ncib;
     const int co0 = cob * BC, ci0 = cib * BC;
     const int total_tiles = p.N * p.tiles_y * p.tiles_x;
 
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     // vmcnt) and sit in registers during MFMA(k).  Each thread stages its own slots of the double-buffered LDS image;
     // the barrier at the end of iteration k separates the writes of buffer (k+1)&1 from its reads in iteration k+1
     // and from its last reads in k-1.
-    int tile = blockIdx.y, n = 0, ty0 = 0, tx0 = 0, cur = 0;
+    int tile = by, n = 0, ty0 = 0, tx0 = 0, cur = 0;
     int pn = 0, pty0 = 0, ptx0 = 0;                           // group 1: tile whose operands are in registers
     if (tile < total_tiles) {
         decode(tile, n, ty0, tx0);
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     // at ~1.3 TB/s chip-wide: 38 MB of them per launch cost 25-36 us, the slab stores + the reduction about half.
     if (p.wsp) {
         if (!(p.dbg & 1)) {
-            float* wsb = p.wsp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * (NT0 * 16 * 64) + lane;
+            float* wsb = p.wsp + ((size_t)(by * gridDim.x + bx) * 8 + wave) * (NT0 * 16 * 64) + lane;
 #pragma unroll
             for (int j = 0; j < NT0; ++j)
 #pragma unroll
