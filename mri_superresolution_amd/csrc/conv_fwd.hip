@@ -234,6 +234,41 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
         }
     };
+#ifndef MRISR_NO_DMA_WEIGHTS
+#define MRISR_DMA_WEIGHTS 1
+#endif
+#ifdef MRISR_DMA_WEIGHTS
+    // The streamed weight image by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, global ->
+    // LDS with no register staging and no ds_write).  The packed image is already the LDS image byte for byte, so piece
+    // q is a linear 1 KiB copy.  Inline asm: hipcc's own waitcnt bookkeeping does not see it (in-order retirement makes
+    // that safe: an unknown older operation can only make its counted waits longer), the completion wait is explicit.
+    // Half 0 issues the image of item c + 1 at the start of its matrix phase of item c - image (c + 1) & 1 was last read
+    // two ticks earlier - and waits for it at the start of its next vector phase; both halves read it after the barrier.
+    // Measured against the register-staged variant (each half loading / storing every other image): same results, 204
+    // instead of 244 VGPRs, streamed-weights kernel 108.5 -> 107.7 us inside the step (-DMRISR_NO_DMA_WEIGHTS builds that
+    // variant).
+    auto dma_weights = [&](int kc, int item) {
+        if (p.dbg & (4 | 256)) return;
+        if constexpr (!WS) {
+            constexpr int NPIECE = WIMG_VECS * 16 / 1024;
+            const int kcs = __builtin_amdgcn_readfirstlane(kc), its = __builtin_amdgcn_readfirstlane(item);
+            const int w0 = __builtin_amdgcn_readfirstlane(wave);
+            const char* src = wbase + (size_t)kcs * (WIMG_VECS * 16) + lane * 16;
+            const unsigned dst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_w + (unsigned)(its & 1) * (WIMG_VECS * 16);
+#pragma unroll
+            for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
+                const int piece = w0 + 4 * j;
+                if (piece < NPIECE) {
+                    unsigned keep;
+                    const char* g = src + piece * 1024;
+                    const unsigned d = dst0 + piece * 1024;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+                }
+            }
+        }
+    };
+#endif
     auto issue = [&](int n, int kc, int ty0, int tx0) {
         if (p.dbg & 4) return;
         if constexpr (NH == 1) {
@@ -577,9 +612,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         set_geom(cur_n, cur_ty0, cur_tx0);
         issue(cur_n, 0, cur_ty0, cur_tx0);
     }
+#ifdef MRISR_DMA_WEIGHTS
+    if constexpr (!WS) {
+        if (half == 0 && nitems0 > 0) dma_weights(0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the image is in LDS before the barrier below
+        if constexpr (NH != 1) __syncthreads();
+    }
+#else
     if constexpr (!WS) {
         if (half < nitems0) issue_weights(wkc);
     }
+#endif
     if constexpr (NH == 1) {
         if (wave == 0 && nitems > 0) lds_aff[lane] = pf.aff;     // first item's table; later ones at the end of a matrix phase
         __syncthreads();
@@ -596,9 +639,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         PT_MARK(8)
         if (phase >= 0 && (phase & 1) == 0) {
             // ------------------------------------------------ vector phase
+#ifdef MRISR_DMA_WEIGHTS
+            if constexpr (!WS) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): half 0's image DMA of the last matrix phase has landed
+#else
             if constexpr (!WS) {
                 if (!(c & 1) && c + half < nitems0) store_weights(c + half);
             }
+#endif
             // Order: commit item c (its loads were issued one full tick pair ago) -> issue the loads of item c+1
             // right away (the prefetch registers are free again) -> only then the epilogue of the tile that finished
             // in the previous matrix phase.  The loads thus have the rest of this phase plus the whole matrix phase
@@ -631,6 +678,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             }
         } else if (phase >= 0) {
           // ------------------------------------------------ matrix phase
+#ifdef MRISR_DMA_WEIGHTS
+          if constexpr (!WS) {
+              // half 0, every item: image (c + 1) & 1 (last read two ticks ago) <- weights of item c + 1; it lands during
+              // this matrix phase and is waited for at the start of this half's next vector phase
+              if (half == 0 && c < nitems && c + 1 < nitems0) dma_weights(nxt_kc, c + 1);
+          }
+#else
           if constexpr (!WS) {
               // odd item index: load the image this half stores in its next vector phase (target item c + 1 + half)
               if ((c & 1) && c + 1 + half < nitems0) {
@@ -644,6 +698,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                   for (int j = 0; j < NW; ++j) asm volatile("" : "=v"(pf.w[j].v));
               }
           }
+#endif
           if (c < nitems) {
             const char* wl = lds_w + (size_t)(WS ? cur_kc : (c & 1)) * (WIMG_VECS * 16);
             // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
