@@ -24,8 +24,16 @@ __device__ __forceinline__ int halo_off(int row, int chunk) { return row * kHalo
 // forward kernel LDS budget: two halo tiles of kMaxHaloIter*64 rows (every commit slot has a row, so the LDS stores
 // need no bounds predicate) + the weight images + BN floats of bias
 static inline size_t conv_halo_bytes() { return (size_t)kMaxHaloIter * 64 * kHaloRowBytes; }
+// bf16 plain epilogue staging: 4 waves x 32 pixel rows x (64 couts x 2 B + 16 B pad)
+static inline size_t conv_stage_bytes() {
+#ifdef MRISR_STAGED_STORES
+    return 4 * 32 * (64 * 2 + 16);
+#else
+    return 0;
+#endif
+}
 static inline bool conv_weights_stationary(int nchunks, size_t wimg) {
-    return nchunks * wimg + 2 * conv_halo_bytes() + (64 + 128) * sizeof(float) <= 158 * 1024;   // + bias, affine tables
+    return nchunks * wimg + 2 * conv_halo_bytes() + (64 + 128) * sizeof(float) + conv_stage_bytes() <= 159 * 1024;   // + bias, affine tables, staging
 }
 // wgrad kernel variant: 0 = generic, 1 / 2 / 4 = FAST with that k-step interleave (bf16 3x3 plain loader, 8x32 tiles,
 // every channel block of the launch holding the same number of 32x32 fragment pairs)

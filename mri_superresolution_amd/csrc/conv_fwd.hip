@@ -102,6 +102,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     float* lds_bias = reinterpret_cast<float*>(smem + 2 * halo_bytes + (WS ? p.nchunks : 2) * (WIMG_VECS * 16));   // [BN]
     // plain loader: GroupNorm scale (entries 0..31) / shift (32..63) of the cin chunk this half commits next
     float* lds_aff = lds_bias + BN + half * 64;
+    // (experiment, -DMRISR_STAGED_STORES, measured -0.7 % on the step and left off: coalescing the output stores does
+    // not make them cheaper, the extra LDS round trip costs more than it saves)
+    // bf16 plain epilogue: per-wave staging rows ([32 pixels][BN couts], 16 B of padding per row) through which a
+    // fragment's outputs are re-read pixel-contiguously, so that one store instruction writes whole 128-byte lines
+    // (8 lanes per pixel) instead of 64 scattered 16-byte pieces; shared by the halves (their vector phases alternate)
+    constexpr int kStageRow = BN * 2 + 16;
+    char* lds_stage = reinterpret_cast<char*>(lds_bias + BN + 128) + (threadIdx.x >> 6 & 3) * (32 * kStageRow);
 
     // this workgroup: one cout block, tiles [bt0, bt1); this half: [tile0, tile1)
     // XCD-aware order: workgroup b runs on XCD b % 8, so the logical index (b % 8) * (grid / 8) + b / 8 puts CONSECUTIVE
@@ -551,6 +558,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                         auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                         u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+#ifdef MRISR_STAGED_STORES
+                        // stage: row = pixel (lr), column = this lane's 8 channels
+                        *reinterpret_cast<u32x4*>(lds_stage + lr * kStageRow + (ni * 32 + 8 * (q + lh_e)) * 2) = o;
+                        continue;
+#endif
                         const int co8 = bn0 + ni * 32 + 8 * (q + lh_e);      // first of the 8 channels this lane now owns
                         const unsigned ob = loff + (ni * 32 + 8 * q) * (unsigned)sizeof(T);
                         if (pv && co8 < p.Cout && !(p.dbg & 1)) {
@@ -592,6 +604,34 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 }
                 __builtin_amdgcn_sched_barrier(0);   // bound the scheduling window: one (mi, ni) group's temporaries live at a time
             }
+#ifdef MRISR_STAGED_STORES
+            if constexpr (!kPSE && sizeof(T) == 2) {
+                constexpr int CH = BN / 8, PPI = 64 / CH, NIT = 32 / PPI;     // 16-B chunks per pixel, pixels per store, stores
+                const int chunk = lane & (CH - 1), prow = lane / CH;
+                const bool cv = bn0 + chunk * 8 < p.Cout;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int pp = it * PPI + prow;                           // pixel (row of the staging tile) of this lane
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(lds_stage + pp * kStageRow + chunk * 16);
+                    const int pl2 = wave * 64 + mi * 32 + pp;
+                    const int py2 = pl2 >> p.tw_log2, px2 = pl2 & (TW - 1);
+                    const unsigned o2 = mad_u24(mad_u24(py2, p.W, px2), p.Cout * 2u, chunk * 16u);
+                    if (ty0 + py2 < p.H && tx0 + px2 < p.W && cv && !(p.dbg & 1)) {
+                        u32x4 o = v;
+                        if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
+                            const u32x4 m = gload<u32x4>(mbase + o2);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const unsigned lo = __uint_as_float(m[k] << 16) > 0.f ? 0x0000ffffu : 0u;
+                                const unsigned hi = __uint_as_float(m[k] & 0xffff0000u) > 0.f ? 0xffff0000u : 0u;
+                                o[k] &= (lo | hi);
+                            }
+                        }
+                        gstore(obase + o2, o);
+                    }
+                }
+            }
+#endif
         }
     };
     // ---- schedule: commit phase c at tick 2c + half, MFMA phase c at tick 2c + 1 + half
@@ -979,7 +1019,7 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
     const size_t wimg = (size_t)KS * KS * BN * kRowBytes;
     // weights-stationary when every cin chunk fits next to the two halo tiles
     p.ws = conv_weights_stationary(p.nchunks, wimg) ? 1 : 0;
-    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg + (BN + 128) * sizeof(float);
+    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg + (BN + 128) * sizeof(float) + conv_stage_bytes();
     p.ntiles = p.N * p.tiles_y * p.tiles_x;
     int per_cb = num_cus() / p.ncb;                     // persistent workgroups per cout block, one per CU
     if (per_cb < 1) per_cb = 1;
