@@ -51,6 +51,24 @@ def test_conv3x3_raw(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,ks", [((1, 224, 32, 20, 40), 3),     # 32-cout block, streamed weights: 18 one-KiB image pieces
+                                      ((1, 288, 64, 20, 40), 3),     # 64-cout block, 9 cin chunks, odd tile count per half
+                                      ((2, 800, 64, 12, 20), 1),     # 1x1 with streamed weights: 4 pieces per image
+                                      ((1, 832, 24, 9, 33), 1)])     # 1x1, 32-cout block (2 pieces), Cout < block
+def test_conv_streamed_weight_images(dt, shape, ks):
+    """Convs whose weight images do not fit LDS next to the halo tiles (streamed by LDS-DMA, two images shared by the
+    halves): piece counts that are not a multiple of the 4 issuing waves, odd item counts, partial cout blocks."""
+    n, cin, cout, h, w = shape
+    x, wt = rnd(n, cin, h, w, seed=11), rnd(cout, cin, ks, ks, seed=12, scale=0.05)
+    out, stats = U.conv_forward(dt, [U.SrcSpec(x)], wt, h, w, ks)
+    ref = F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), padding=ks // 2)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    o = ref.view(n, 8, cout // 8, h, w).double()
+    loose = dt == L.BF16 and (cout // 8) % 4 != 0
+    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=(3e-2 if loose else 1e-3) * o.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_conv1x1_and_bias(dt):
     n, cin, cout, h, w = 2, 64, 32, 20, 36
     x, wt, b = rnd(n, cin, h, w, seed=3), rnd(cout, cin, 1, 1, seed=4, scale=0.2), rnd(cout, seed=5)
