@@ -11,6 +11,7 @@ concat, pixel-shuffle and the alpha blend live inside the convolution loaders/ep
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -29,6 +30,10 @@ def _dt(dtype: torch.dtype) -> int:
     if dtype == torch.float32:
         return L.F32
     raise ValueError(f"unsupported compute dtype {dtype} (use torch.float32 or torch.bfloat16)")
+
+
+# order of the two convolutions of a layer's backward step (tuning: MRISR_WGRAD_LAST=1 runs dgrad first)
+_WGRAD_LAST = os.environ.get("MRISR_WGRAD_LAST", "0") == "1"
 
 
 @dataclass
@@ -482,9 +487,13 @@ class UNetEngine:
             ws = getattr(self, "_wgrad_ws", None)
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self._wgrad_ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
-            self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
-                                                    grads[layer.name + ".weight"].data_ptr(), ws.data_ptr(),
-                                                    ws.numel(), st))
+            def launch_wgrad():
+                self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
+                                                        grads[layer.name + ".weight"].data_ptr(), ws.data_ptr(),
+                                                        ws.numel(), st))
+            wgrad_last = _WGRAD_LAST
+            if not wgrad_last:
+                launch_wgrad()
             if layer.bias and not fuse_bias:
                 L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
                        N * layer.H * layer.W, layer.cout, st)
@@ -500,6 +509,8 @@ class UNetEngine:
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
             self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))
+            if wgrad_last:
+                launch_wgrad()
             if layer.combine == L.COMBINE_BLEND:
                 a, b = layer.srcs[0].node, layer.srcs[1].node
                 a.consumers.append((dain, layer.cin, 0, layer.H, layer.W, L.SP_NONE, 0, 0, 1))
