@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: 2-D MRI slices/s of the U-Net super-resolution TRAIN step on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps 20 --warmup 5        # N > 1: this process only LAUNCHES (see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -17,12 +17,13 @@ Prints ONE JSON line on rank 0 (see the repo prompt for the schema) with two ext
 `cpu_baseline` (the oracle port timed on this box's host cores, rank 0 at N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -66,9 +67,23 @@ def cpu_baseline(base_filters, size, ssim_weight):
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
-    return {"value": round(batch * n / dt, 4), "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"oracle torch-CPU fp32 train step, base_filters={base_filters}, {size}x{size}->{2 * size}x{2 * size}, "
-                      f"batch {batch}, L1+SSIM({ssim_weight}), 1 warm-up + {n} timed steps, {dt / n * 1e3:.0f} ms/step"}
+    rec = {"value": round(batch * n / dt, 4), "unit": "slices/s", "cores": threads, "kind": "port",
+           "sample": f"oracle torch-CPU fp32 train step, base_filters={base_filters}, {size}x{size}->{2 * size}x{2 * size}, "
+                     f"batch {batch}, L1+SSIM({ssim_weight}), 1 warm-up + {n} timed steps, {dt / n * 1e3:.0f} ms/step"}
+    # BASELINE configs[0] (the reference's own CPU-runnable case): f=32, 128x128 -> 256x256, batch 4,
+    # L1 only, fp32 - timed beside the headline shapes so that it is measured somewhere on this box
+    step1 = cpu_train_step_fn(32, 4, 128, 128, 0.0, threads=threads)
+    for _ in range(2):
+        step1()
+    t0 = time.perf_counter()
+    n1 = 10
+    for _ in range(n1):
+        step1()
+    dt1 = time.perf_counter() - t0
+    rec["c1"] = {"value": round(4 * n1 / dt1, 3), "unit": "slices/s",
+                 "sample": f"BASELINE configs[0]: base_filters=32, 128x128->256x256, batch 4, L1-only, 2 warm-up + {n1} "
+                           f"timed steps, {dt1 / n1 * 1e3:.0f} ms/step"}
+    return rec
 
 
 def unet_flops_fwd(f, H, W, depth=4):
@@ -80,26 +95,65 @@ def unet_flops_fwd(f, H, W, depth=4):
     return U * (1.0 / f + 1.0 + (depth - 1) * 1.5 + (depth - 1) * (2.0 / 9.0 + 3.0) + 5.0 + 2.0 / (9.0 * f))
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
-    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, with the gfx950
-    corrections of MI355X_MICROARCH.md); None when that kernel has not been measured."""
+def csrc_sha16():
+    """Hash of the kernel sources: PMC traffic figures are only valid for the kernels they were measured on."""
+    d = os.path.join(REPO, "mri_superresolution_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """profiles/pmc_traffic.json (tools/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command, gfx950 x2 read correction of MI355X_MICROARCH.md).  Returns (table, provenance); the table is None -
+    and every traffic figure in the line null - when the kernel sources changed after the passes were taken."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+            j = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/pmc_traffic.json"
+    have, now = j.get("csrc_sha16"), csrc_sha16()
+    if have != now:
+        return None, f"stale: PMC passes taken at csrc {have}, kernels now {now}"
+    return j, f"rocprofv3 PMC passes at csrc {have} ({j.get('command', 'bench.py')})"
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` typed directly (no WORLD_SIZE in the environment): this parent makes NO GPU call (it
+    never imports torch); it starts `python -m torch.distributed.run` with N fresh rank processes as a child, relays its
+    output (rank 0 prints the JSON line) and exits with its return code."""
+    cmd = rank_launch_command(args.gpus, sys.argv[1:], free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env, cwd=os.getcwd()).returncode
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def rank_launch_command(n, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -203,6 +257,36 @@ def main():
         model._engine.timer = None
         if vgg_eng is not None:
             vgg_eng.timer = None
+    # ---- step time WITHOUT the gradient exchange (same steps, all-reduce skipped: ranks diverge, timing only)
+    noex_elapsed = None
+    if dp is not None and not args.forward_only:
+        sync()
+        t2 = time.perf_counter()
+        with dp.no_sync():
+            for _ in range(args.steps):
+                step()
+        sync()
+        noex_elapsed = time.perf_counter() - t2
+        tt = torch.tensor([noex_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        noex_elapsed = float(tt.item())
+    # ---- forward-only metric (scripts/infer.py:268-276: eval forward, no_grad) in the same run, same batch
+    fwd_elapsed, fwd_steps = None, 20
+    if not args.forward_only:
+        model.eval()
+        for _ in range(3):
+            fwd_step()
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(fwd_steps):
+            fwd_step()
+        sync()
+        fwd_elapsed = time.perf_counter() - t3
+        if world > 1 or force_dp:
+            tt = torch.tensor([fwd_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            fwd_elapsed = float(tt.item())
+        model.train()
     if world > 1 or force_dp:
         dist.barrier()
 
@@ -227,8 +311,24 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "conv_flops_per_slice": flops_slice,
                        "model_tflops": round(value * flops_slice / 1e12, 2),
-                       "frac_of_mfma_peak": round(value * flops_slice / 1e12 / (world * MFMA_PEAK_TFLOPS[args.dtype]), 4)},
+                       "frac_of_mfma_peak": round(value * flops_slice / 1e12 / (world * MFMA_PEAK_TFLOPS[args.dtype]), 4),
+                       "flop_convention": "SURVEY.md 8(d) algorithmic FLOPs: the Up blocks' 1x1 convs are counted at the "
+                                          "upsampled resolution as the reference runs them; this build runs them before "
+                                          "the bilinear x2 (4x fewer), so executed MFMA FLOPs are ~2.5 % below this figure"},
         }
+        if fwd_elapsed is not None:
+            fv = world * B * fwd_steps / fwd_elapsed
+            rec["forward"] = {"slices_per_s": round(fv, 1), "ms_per_batch": round(fwd_elapsed / fwd_steps * 1e3, 3),
+                              "batch": B, "steps": fwd_steps,
+                              "model_tflops": round(fv * f_fwd / 1e12, 1),
+                              "frac_of_mfma_peak": round(fv * f_fwd / 1e12 / (world * MFMA_PEAK_TFLOPS[args.dtype]), 4),
+                              "what": "eval forward (scripts/infer.py:268-276), same model / batch, timed after the train steps"}
+        if dp is not None:
+            rec["collective"] = {"backend": dist.get_backend(), "world": world,
+                                 "allreduce_bytes_per_step": int(model.flat_grads.numel() * 4),
+                                 "buckets": len(dp.bucketer.bounds) - 1,
+                                 "ms_per_step_with_exchange": round(ms, 3),
+                                 "ms_per_step_without_exchange": None if noex_elapsed is None else round(noex_elapsed / args.steps * 1e3, 3)}
         if timer is not None:
             summ = timer.summary()
             if summ:
@@ -240,7 +340,11 @@ def main():
                                    "flops_per_launch": dom["flops_per_launch"],
                                    "timing": f"HIP events on the launch stream, separate pass of {timed_steps} steps "
                                              f"({timed_elapsed / timed_steps * 1e3:.3f} ms/step instrumented)"}
-                rec["roofline"]["traffic"] = pmc_traffic(name)
+                table, prov = pmc_traffic()
+                rec["roofline"]["traffic_provenance"] = prov
+                if table is not None:
+                    rec["roofline"]["traffic"] = table.get("kernels", {}).get(name, {}).get("hbm_bytes_per_launch")
+                    rec["hbm_bytes_per_step"] = table.get("hbm_bytes_per_step")
                 rec["kernels"] = {k: {"launches": v["launches"], "us_per_launch": round(v["ms_per_launch"] * 1e3, 2),
                                       "tflops": round(v["tflops"], 2), "share_of_step": round(v["total_ms"] / (timed_elapsed * 1e3), 4)}
                                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}

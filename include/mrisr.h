@@ -14,7 +14,9 @@
  *  - errors    : every entry returns int (0 = ok, <0 = MRISR_E_*); mrisr_last_error()
  *                returns a thread-local message.
  *  - streams   : asynchronous launch on the caller's HIP stream (void* = hipStream_t),
- *                no internal synchronisation, no global mutable state.
+ *                no internal synchronisation; re-entrant.  Process-wide state is limited to
+ *                once-initialised constants (CU count, per-kernel LDS-size attributes, both
+ *                behind std::call_once / magic statics); the library reads no environment variable.
  *  - layout    : activations NHWC ("channels last"), dtype MRISR_BF16 or MRISR_F32;
  *                conv weights [Cout][kh][kw][Cin] fp32 masters (= torch channels_last
  *                storage of a (Cout,Cin,kh,kw) tensor); statistics double / fp32.
@@ -90,6 +92,8 @@ typedef struct {
 
 const char* mrisr_last_error(void);
 int mrisr_version(void);
+/* the MRISR_STAT_SLOTS this library was compiled with (the caller sizes the statistics buffers with it) */
+int mrisr_stat_slots(void);
 
 /* ---- convolution: replaces nn.Conv2d forward (unet_model.py:29,34,72,101,152,168) and, with
  *      flipped/transposed packed weights and a RAW source, its input-gradient. ------------- */

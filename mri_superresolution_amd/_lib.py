@@ -13,7 +13,7 @@ SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
 SP_NONE, SP_POOL2, SP_UP2 = 0, 1, 2
 COMBINE_CONCAT, COMBINE_BLEND = 0, 1
 OUT_PLAIN, OUT_PIXEL_SHUFFLE2 = 0, 1
-STAT_SLOTS = int(os.environ.get("MRISR_STAT_SLOTS", "16"))   # MRISR_STAT_SLOTS (env: tuning builds compiled with another value)
+STAT_SLOTS = 16      # = MRISR_STAT_SLOTS of include/mrisr.h; load() replaces it with the library's compiled value
 
 _vp, _fp, _dp, _i, _f, _d, _sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -47,6 +47,7 @@ class Consumer(C.Structure):
 SIGNATURES = {
     "mrisr_last_error": (C.c_char_p, []),
     "mrisr_version": (_i, []),
+    "mrisr_stat_slots": (_i, []),
     "mrisr_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mrisr_pack_weights": (_i, [_i, _fp, _i, _i, _i, _i, _vp, _vp]),
     "mrisr_pack_weights_batched": (_i, [_i, _vp, _i, _vp]),
@@ -102,6 +103,10 @@ def load():
         fn = getattr(lib, name)       # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
+    global STAT_SLOTS
+    if hasattr(lib, "mrisr_stat_slots"):
+        # the statistics arenas are sized with this: it must be the value the kernels were compiled with
+        STAT_SLOTS = int(lib.mrisr_stat_slots())
     _lib = lib
     return lib
 

@@ -71,8 +71,15 @@ struct ConvParams {
     int ksplit;       // wgrad only
     int ws;           // forward: all cin chunks of the weight image stay resident in LDS
     int ntiles, tiles_per_block;   // forward: persistent blocks own contiguous tile ranges
-    int dbg;          // tuning ablations (env MRISR_DEBUG): 1 no stores, 2 no LDS commit, 4 no global loads, 8 no MFMA
+    int dbg;          // tuning builds only (-DMRISR_TUNING, env MRISR_DEBUG): 1 no stores, 2 no LDS commit, 4 no global loads, 8 no MFMA
 };
+// Ablation bits exist in tuning builds only (tools/build_prof.sh): the product library never reads the environment
+// and compiles every `DBG(p) & bit` test away.
+#ifdef MRISR_TUNING
+#define DBG(p) ((p).dbg)
+#else
+#define DBG(p) 0
+#endif
 
 // hipcc re-loads kernel arguments with s_load + s_waitcnt at every use inside long loops (they are "free" to
 // rematerialise); pinning the hot ones as opaque scalars keeps them in SGPRs instead.

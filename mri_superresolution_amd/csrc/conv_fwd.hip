@@ -14,6 +14,7 @@
 // materialised" (pooled / upsampled / blended inputs of the narrow layers) are listed in DESIGN.md section 3.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     };
     int upflags = 0;      // UP2 gather prefetch: bit 2i = second row differs, bit 2i+1 = second column differs
     auto set_geom = [&](int n, int ty0, int tx0) {
-        if (p.dbg & 32) return;
+        if (DBG(p) & 32) return;
         if constexpr (NH == 1) return;     // plain loader: addresses are derived per item from scalars (see issue)
 #pragma unroll
         for (int i = 0; i < kMaxHaloIter; ++i)
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // streamed weights (not weights-stationary): the next chunk's image, issued at the start of the matrix phase
     // (L2-resident, and keeping these 36 VGPRs dead during the epilogue avoids spills)
     auto issue_weights = [&](int kc) {
-        if (p.dbg & (4 | 256)) return;     // (ablation: 256 = no weight loads)
+        if (DBG(p) & (4 | 256)) return;     // (ablation: 256 = no weight loads)
         if constexpr (!WS) {
             const u32x4* wsrc = reinterpret_cast<const u32x4*>(wbase + (size_t)kc * (WIMG_VECS * 16));
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         }
     };
     auto store_weights = [&](int item) {     // prefetched image -> LDS image (item & 1)
-        if (p.dbg & 128) return;             // (ablation: 128 = no weight LDS stores)
+        if (DBG(p) & 128) return;             // (ablation: 128 = no weight LDS stores)
         if constexpr (!WS) {
             char* dst = lds_w + (size_t)(item & 1) * (WIMG_VECS * 16);
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // instead of 244 VGPRs, streamed-weights kernel 108.5 -> 107.7 us inside the step (-DMRISR_NO_DMA_WEIGHTS builds that
     // variant).
     auto dma_weights = [&](int kc, int item) {
-        if (p.dbg & (4 | 256)) return;
+        if (DBG(p) & (4 | 256)) return;
         if constexpr (!WS) {
             constexpr int NPIECE = WIMG_VECS * 16 / 1024;
             const int kcs = __builtin_amdgcn_readfirstlane(kc), its = __builtin_amdgcn_readfirstlane(item);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     };
 #endif
     auto issue = [&](int n, int kc, int ty0, int tx0) {
-        if (p.dbg & 4) return;
+        if (DBG(p) & 4) return;
         if constexpr (NH == 1) {
             // Plain loader.  Everything is derived per item from wave-uniform scalars (image, tile origin, chunk: SALU
             // after the readfirstlanes) and the packed halo-slot coordinates: no per-tile geometry registers, no 64-bit
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     };
     // transform + store the prefetched item into LDS (gather modes: stage synchronously)
     auto commit = [&](int n, int kc, int ty0, int tx0) {
-        if (p.dbg & 2) return;
+        if (DBG(p) & 2) return;
         if constexpr (NH == 1) {
             // straight-line: y = x*sc+sh, act = max(y, slope*y), unpredicated 16-B LDS
             // store of every slot; the slots that must read as zero (conv padding, channels beyond Cin) are then
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // outside the image and channels >= Cout are handled by multiplying the statistics with 0/1 and by predicating
     // only the stores); bias / ReLU sit behind one block-uniform branch per fragment.
     auto epilogue = [&](int n_v, int ty0_v, int tx0_v) {
-        if (p.dbg & 16) return;
+        if (DBG(p) & 16) return;
         // Addresses: scalar base of (image, tile origin, first channel of this cout block) - SALU after the
         // readfirstlanes - plus one 32-bit per-lane byte offset per pixel row (two 24-bit mads) plus compile-time
         // constants for the fragment / quad: no 64-bit per-lane arithmetic in front of the stores.
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         union { bf16x4 b; u32x2 u; } cv;
                         cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         packed[q] = cv.u;
-                    } else if (pv && co < p.Cout && !(p.dbg & 1)) {
+                    } else if (pv && co < p.Cout && !(DBG(p) & 1)) {
                         if constexpr (!kPSE) {
                             const unsigned o = loff + (ni * 32 + 8 * q) * (unsigned)sizeof(T);
                             if constexpr (EPI == kEpiMask) {   // ReLU backward: keep the gradient where the activation is > 0
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
 #endif
                         const int co8 = bn0 + ni * 32 + 8 * (q + lh_e);      // first of the 8 channels this lane now owns
                         const unsigned ob = loff + (ni * 32 + 8 * q) * (unsigned)sizeof(T);
-                        if (pv && co8 < p.Cout && !(p.dbg & 1)) {
+                        if (pv && co8 < p.Cout && !(DBG(p) & 1)) {
                             if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
                                 const u32x4 m = gload<u32x4>(mbase + ob);
 #pragma unroll
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         const u32x2 o = {(X & 0xffffu) | (Y << 16), (X >> 16) | (Y & 0xffff0000u)};
                         // scalar: sub-pixel (i, j) and the fragment's first c'
                         char* ob = obase + (((size_t)(ij >> 1) * (2 * p.W) + (ij & 1)) * C4 + ni * 8) * sizeof(T);
-                        if (pv && okc && !(p.dbg & 1)) gstore(ob + loff, o);
+                        if (pv && okc && !(DBG(p) & 1)) gstore(ob + loff, o);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // bound the scheduling window: one (mi, ni) group's temporaries live at a time
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     const int pl2 = wave * 64 + mi * 32 + pp;
                     const int py2 = pl2 >> p.tw_log2, px2 = pl2 & (TW - 1);
                     const unsigned o2 = mad_u24(mad_u24(py2, p.W, px2), p.Cout * 2u, chunk * 16u);
-                    if (ty0 + py2 < p.H && tx0 + px2 < p.W && cv && !(p.dbg & 1)) {
+                    if (ty0 + py2 < p.H && tx0 + px2 < p.W && cv && !(DBG(p) & 1)) {
                         u32x4 o = v;
                         if constexpr (EPI == kEpiMask) {   // ReLU backward on packed bf16 pairs
                             const u32x4 m = gload<u32x4>(mbase + o2);
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             // out of the persistent loop into 36 VGPRs
             asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
 #ifndef MRISR_NO_PIPE_MMA
-            if (!(p.dbg & 8)) {
+            if (!(DBG(p) & 8)) {
                 // 2 * NTAPS steps of (2 pixel fragments, NF weight fragments, 2 * NF MFMAs), software-pipelined by one step
                 // with two fragment sets: the LDS reads of step s+1 are issued before the MFMAs of step s; the order is
                 // pinned with sched_group_barrier (hipcc otherwise sinks the reads back next to their use and waits for
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 }
             }
 #else
-            if (!(p.dbg & 8)) {
+            if (!(DBG(p) & 8)) {
 #pragma unroll
                 for (int tap = 0; tap < NTAPS; ++tap) {
                     const int tapoff = ((tap / KS) * hw + (tap % KS)) * kHaloRowBytes;
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
           }
             PT_MARK(6)
         }
-        if (!(p.dbg & 64)) __syncthreads();
+        if (!(DBG(p) & 64)) __syncthreads();
 #ifdef MRISR_PHASE_TIMING
         if (phase >= 0 && (phase & 1) == 0) PT_MARK(5) else PT_MARK(7)
 #endif
@@ -992,21 +993,23 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
     p.ncb = ceil_div(d->Cout, BN); p.CoutP = p.ncb * BN;
     p.nsrc = d->nsrc; p.combine = d->combine; p.out_mode = d->out_mode; p.groups = d->stats ? d->groups : 0;
     p.relu_out = d->relu_out;
-    { const char* e = getenv("MRISR_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+#ifdef MRISR_TUNING
+    { static const int dbg_env = [] { const char* e = getenv("MRISR_DEBUG"); return e ? atoi(e) : 0; }(); p.dbg = dbg_env; }
+#endif
     conv_choose_tile(d->W, p.th, p.tw_log2);
     p.tiles_x = ceil_div(d->W, 1 << p.tw_log2); p.tiles_y = ceil_div(d->H, p.th);
     return MRISR_OK;
 }
 
-static int g_num_cus = 0;
+// CU count of the current device (read once; one process drives one GPU - mrisr.h threading contract)
 int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0;
+    static const int n = [] {
+        int dev = 0, cus = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    return g_num_cus;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
 }
 
 int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s);
@@ -1033,8 +1036,8 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
     const bool stats_sep = stats && ((p.Cout / p.groups) & 3);
     if (stats_sep) p.stats = nullptr;
     constexpr bool kPS = (SPATIAL == MRISR_SP_NONE && KS == 3);   // pixel-shuffle epilogue: plain 3x3 convs only
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
+    static std::once_flag attr_once;   // per instantiation
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if constexpr (kPS) {
@@ -1043,8 +1046,7 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
-        attr_set = true;
-    }
+    });
     if (p.out_mode == MRISR_OUT_PIXEL_SHUFFLE2) {
         if constexpr (kPS) {
             if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1>), dim3(grid), dim3(kFwdThreads), lds, s, p);

@@ -18,6 +18,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "conv_common.h"
 
 template <typename T> struct WgTraits;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     // channel vector of this thread inside the conv input for the halo: sub-chunk (ch8>>2), chunk (ch8&3)
     const int c_in = ci0 + ch8 * VEC;
     auto issue = [&](int n, int ty0, int tx0) {
-        if (p.dbg & 4) return;
+        if (DBG(p) & 4) return;
         const int c = co0 + ch8 * VEC;
         int dm = 0;
         // opaque copy of the thread index: the per-slot pixel coordinates are 2 VALU ops each to recompute, hoisted
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
         }
     };
     auto commit = [&](char* buf, int n) {
-        if (p.dbg & 2) return;
+        if (DBG(p) & 2) return;
         char* lds_dy = buf;
         char* lds_in = buf + 256 * 128;
         int tq = t >> 3;                       // opaque: the 10 LDS store addresses are recomputed, not kept live
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     auto mfma_block = [&](auto tg_tag) {      // tg_tag: the (wave-uniform) tap group of the calling site
         const char* lds_dy = smem + cur * buf_bytes;
         const char* lds_in = lds_dy + 256 * 128;
-        if (p.dbg & 8) {
+        if (DBG(p) & 8) {
         } else if constexpr (FAST) {
             if constexpr (decltype(tg_tag)::value == 0) mfma_fast(std::integral_constant<int, 0>{});
             else mfma_fast(std::integral_constant<int, 1>{});
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     // workgroup's slab; wgrad_reduce_kernel sums the split-K slabs.  The float atomics below run at the memory side
     // at ~1.3 TB/s chip-wide: 38 MB of them per launch cost 25-36 us, the slab stores + the reduction about half.
     if (p.wsp) {
-        if (!(p.dbg & 1)) {
+        if (!(DBG(p) & 1)) {
             float* wsb = p.wsp + ((size_t)(by * gridDim.x + bx) * 8 + wave) * (NT0 * 16 * 64) + lane;
 #pragma unroll
             for (int j = 0; j < NT0; ++j)
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
     }
     // ---- accumulate into dW[co][tap][ci]: lane = ci (128-B contiguous per half wave), regs = co
     const int ci = ci0 + fi * 32 + lr;
-    if (ci < p.Cin && !(p.dbg & 1)) {
+    if (ci < p.Cin && !(DBG(p) & 1)) {
 #pragma unroll
         for (int j = 0; j < NT0; ++j) {
             const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);
@@ -478,11 +480,10 @@ static int launch_wgrad(ConvParams& p, hipStream_t s) {
     const size_t need = (size_t)nblk * ksplit * 8 * ((KS * KS + 1) / 2) * 16 * 64;
     if (!(p.wsp && ksplit >= 4 && need <= p_ws_floats)) p.wsp = nullptr;
     auto kern = conv_wgrad_kernel<T, SPATIAL, KS, FAST>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;   // per instantiation
+    std::call_once(attr_once, [kern] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(kern, dim3(nblk, ksplit), dim3(kWgThreads), lds, s, p);
     MRISR_CHECK_LAUNCH("conv_wgrad");
     if (p.wsp) {

@@ -174,7 +174,7 @@ class UNetEngine:
                                  combine=L.COMBINE_BLEND, blend_src=True))
         self.head_in = fc
         self._packed: Dict[tuple, torch.Tensor] = {}
-        self._pack_versions: Dict[tuple, int] = {}
+        self._packed_token = None      # (dtype, weights token) the packed images were built from
         self.timer: Optional[KernelTimer] = None
 
     def _launch(self, kind, desc, fn):
@@ -186,30 +186,28 @@ class UNetEngine:
         self.timer.launch(buf.value.decode(), flops, fn)
 
     # ------------------------------------------------------------------ weights
-    def _packed_weight(self, layer: Layer, params, dt: int, flip: int, stream, force: bool = False):
-        w = params[layer.name + ".weight"]
+    def _packed_buf(self, layer: Layer, w, dt: int, flip: int):
         key = (layer.name, dt, flip)
-        ver = (w.data_ptr(), w._version)
         buf = self._packed.get(key)
         if buf is None or buf.device != w.device:
             nbytes = L.load().mrisr_packed_weight_bytes(dt, layer.cin if flip else layer.cout,
                                                         layer.cout if flip else layer.cin, layer.ks)
             buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
             self._packed[key] = buf
-            self._pack_versions.pop(key, None)
-        if force or self._pack_versions.get(key) != ver:
-            L.call("mrisr_pack_weights", dt, w.data_ptr(), layer.cout, layer.cin, layer.ks, flip, buf.data_ptr(), stream)
-            self._pack_versions[key] = ver
         return buf
 
     def invalidate_packed(self):
         """Forget every packed weight image (the parameter storage moved or was replaced)."""
         self._packed.clear()
-        self._pack_versions.clear()
         self._jobs_key = None
+        self._packed_token = None
 
-    def _pack_all(self, params, dt: int, stream):
-        """Training: every conv weight (forward and mirrored dgrad image) re-packed in ONE launch per step."""
+    def _pack_all(self, params, dt: int, stream, token=None):
+        """Every conv weight (forward and mirrored dgrad image) re-packed in ONE launch.  Training forwards call this
+        every step (the optimiser rewrites the masters through raw pointers); eval forwards call it whenever the
+        model's weights token (storage, optimiser-step / load epoch, parameter version counters) differs from the one
+        the images were packed at - an eval forward after optimizer.step() or load_state_dict() must not see the
+        images of the old weights."""
         dev = params[self.layers[0].name + ".weight"].device
         key = (dt, str(dev), tuple(params[l.name + ".weight"].data_ptr() for l in self.layers))
         if getattr(self, "_jobs_key", None) != key:
@@ -218,13 +216,7 @@ class UNetEngine:
             for layer in self.layers:
                 w = params[layer.name + ".weight"]
                 for flip in (0, 1):
-                    k = (layer.name, dt, flip)
-                    buf = self._packed.get(k)
-                    if buf is None or buf.device != w.device:
-                        nbytes = L.load().mrisr_packed_weight_bytes(dt, layer.cin if flip else layer.cout,
-                                                                    layer.cout if flip else layer.cin, layer.ks)
-                        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-                        self._packed[k] = buf
+                    buf = self._packed_buf(layer, w, dt, flip)
                     j = jobs[i]
                     j.w, j.packed, j.Cout, j.Cin, j.ksize, j.transpose_flip = w.data_ptr(), buf.data_ptr(), layer.cout, layer.cin, layer.ks, flip
                     i += 1
@@ -233,10 +225,7 @@ class UNetEngine:
             self._jobs_n = i
             self._jobs_key = key
         L.call("mrisr_pack_weights_batched", dt, self._jobs_dev.data_ptr(), self._jobs_n, stream)
-        for layer in self.layers:
-            w = params[layer.name + ".weight"]
-            for flip in (0, 1):
-                self._pack_versions[(layer.name, dt, flip)] = (w.data_ptr(), w._version)
+        self._packed_token = (dt, token)
 
     # ------------------------------------------------------------------ descriptors
     def _desc(self, layer: Layer, dt: int, N: int, params) -> L.ConvDesc:
@@ -277,8 +266,9 @@ class UNetEngine:
         return n.H, n.W
 
     # ------------------------------------------------------------------ forward
-    def forward(self, params, x: torch.Tensor, dtype: torch.dtype, training: bool):
-        """x: (N,1,H,W) fp32 contiguous on the GPU.  Returns (out (N,1,2H,2W) fp32, ctx)."""
+    def forward(self, params, x: torch.Tensor, dtype: torch.dtype, training: bool, weights_token=None):
+        """x: (N,1,H,W) fp32 contiguous on the GPU.  Returns (out (N,1,2H,2W) fp32, ctx).
+        ``weights_token``: any hashable that changes whenever a parameter value may have changed (see _pack_all)."""
         dt = _dt(dtype)
         dev = x.device
         N, _, H, W = x.shape
@@ -303,8 +293,8 @@ class UNetEngine:
                    n.scale.data_ptr(), n.shift.data_ptr(), n.meanrstd.data_ptr(), N, n.C, GN_GROUPS, count,
                    GN_EPS, st)
 
-        if training:      # the optimiser rewrites the masters through raw pointers every step -> always repack
-            self._pack_all(params, dt, st)
+        if training or weights_token is None or self._packed_token != (dt, weights_token):
+            self._pack_all(params, dt, st, weights_token)
         # stem
         s = self.stem
         s.N, s.H, s.W = N, H, W
@@ -352,8 +342,7 @@ class UNetEngine:
                 o.H, o.W = vh, vw
             o.raw = torch.empty((N, o.H, o.W, o.C), dtype=dtype, device=dev)
             d = self._desc(layer, dt, N, params)
-            # training: the optimiser rewrites the masters through raw pointers every step -> always repack
-            d.wpacked = self._packed_weight(layer, params, dt, 0, st).data_ptr()
+            d.wpacked = self._packed[(layer.name, dt, 0)].data_ptr()
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
             if layer.post_up:
                 zlow = torch.empty((N, vh, vw, o.C), dtype=dtype, device=dev)
@@ -505,7 +494,7 @@ class UNetEngine:
             dd.src[0].ptr = dy.data_ptr()
             dd.src[0].C, dd.src[0].H, dd.src[0].W = layer.cout, layer.H, layer.W
             dd.src[0].mode, dd.src[0].spatial = L.SRC_RAW, L.SP_NONE
-            dd.wpacked = self._packed_weight(layer, params, dt, 1, st).data_ptr()
+            dd.wpacked = self._packed[(layer.name, dt, 1)].data_ptr()
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
             self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))

@@ -102,7 +102,8 @@ class _UNetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, hook, model):
-        out, saved = model._engine.forward(model._param_dict(), x, model._resolve_dtype(), training=True)
+        out, saved = model._engine.forward(model._param_dict(), x, model._resolve_dtype(), training=True,
+                                           weights_token=model._weights_token())
         ctx.model = model
         ctx.saved = saved
         return out
@@ -160,6 +161,7 @@ class UNetSuperRes(nn.Module):
         self._engine = UNetEngine(base_filters, in_channels, out_channels, depth)
         self.compute_dtype = None          # None: bf16 under torch.autocast, else fp32
         self.grad_ready_hook = None        # callable(layer_name) for data-parallel overlap
+        self.backward_start_hook = None    # callable(fresh: bool), see parallel.DataParallel
         self.flat_params = None
         self.flat_grads = None
         self._grad_views = None
@@ -210,6 +212,7 @@ class UNetSuperRes(nn.Module):
         self._grad_hook = torch.zeros(1, device=dev, requires_grad=True)
         self._engine.invalidate_packed()
         self._pd_key = None
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn, recurse)
@@ -225,6 +228,21 @@ class UNetSuperRes(nn.Module):
             self._pd_cache = OrderedDict((k, p.data) for k, p in self.named_parameters())
             self._pd_key = key
         return self._pd_cache
+
+    def _weights_token(self):
+        """Changes whenever a conv weight may have changed: the flat storage, the epoch that raw-pointer writers bump
+        (FusedAdam.step, _flatten) and the autograd version counters of the Parameters (load_state_dict, nn.init and
+        torch.optim optimisers write through the Parameter and bump them).  The engine re-packs its weight images when
+        the token differs from the one they were packed at.  Writes through ``p.data`` bypass both: call
+        ``mark_weights_changed()`` after such a write."""
+        wl = getattr(self, "_wt_params", None)
+        if wl is None or self._wt_key != self.flat_params.data_ptr():
+            wl = self._wt_params = [p for p in self.parameters() if p.dim() == 4]
+            self._wt_key = self.flat_params.data_ptr()
+        return (self._wt_key, self._weights_epoch, tuple(p._version for p in wl))
+
+    def mark_weights_changed(self):
+        self._weights_epoch += 1
 
     def _resolve_dtype(self):
         if self.compute_dtype is not None:
@@ -254,7 +272,8 @@ class UNetSuperRes(nn.Module):
         xin = self._check_input(x)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _UNetFunction.apply(xin, self._grad_hook, self)
-        out, _ = self._engine.forward(self._param_dict(), xin, self._resolve_dtype(), training=False)
+        out, _ = self._engine.forward(self._param_dict(), xin, self._resolve_dtype(), training=False,
+                                      weights_token=self._weights_token())
         return out
 
     def graphed_forward(self, example: torch.Tensor):
@@ -289,6 +308,8 @@ class UNetSuperRes(nn.Module):
         named = list(self.named_parameters())
         fresh = all(p.grad is None for _, p in named)
         ours = all(p.grad is None or p.grad.data_ptr() == self._grad_views[k].data_ptr() for k, p in named)
+        if self.backward_start_hook is not None:
+            self.backward_start_hook(fresh)
         if fresh:
             self.flat_grads.zero_()
             target = self._grad_views

@@ -52,6 +52,7 @@ class FusedAdam(torch.optim.Optimizer):
                self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
                float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, float(self.grad_scale),
                L.stream_ptr())
+        m.mark_weights_changed()        # the kernel wrote the masters through raw pointers: packed images are stale
         return loss
 
     # ---- torch.optim.Adam-compatible checkpoint format

@@ -12,6 +12,7 @@ Adam kernel (``FusedAdam.grad_scale``).
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List, Optional
 
 import torch
@@ -95,12 +96,51 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         dist.broadcast(model.flat_params, src=0, group=group)
+        model.mark_weights_changed()
         self.bucketer = GradBucketer(model.flat_grads, model._offsets, bucket_bytes, group)
-        model.grad_ready_hook = self.bucketer.on_layer_done
+        self._sync = True
+        self._reduced = False          # flat_grads currently holds an all-reduced sum
+        model.grad_ready_hook = self._on_layer_done
+        model.backward_start_hook = self._on_backward_start
+
+    # ---- hooks called by UNetSuperRes._run_backward
+    def _on_backward_start(self, fresh: bool):
+        """``fresh``: this backward starts from zeroed gradients.  Accumulating a local micro-batch gradient on top of a
+        buffer that was already summed over ranks and reducing it again would count the earlier micro-batches
+        world_size times."""
+        if fresh:
+            self._reduced = False
+        elif self._reduced:
+            raise RuntimeError("backward() accumulates onto gradients that were already all-reduced: run all but the "
+                               "last micro-batch under `with dp.no_sync():` (or zero_grad() between steps)")
+
+    def _on_layer_done(self, layer_name: str):
+        if self._sync:
+            self.bucketer.on_layer_done(layer_name)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate locally; the first backward
+        outside it all-reduces the accumulated sum (same contract as torch DDP.no_sync)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
 
     def finish_gradients(self):
         """Call after loss.backward(): all buckets reduced (summed) when this returns (stream-wise)."""
+        if not self._sync:
+            return
         self.bucketer.finish()
+        self._reduced = True
+
+    def sum_scalars(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum over ranks of a small tensor (e.g. (sum of per-batch losses, batch count) pairs: dividing the reduced
+        sums once weights every batch equally even when the ranks' shards are uneven or empty)."""
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def average_scalars(self, t: torch.Tensor) -> torch.Tensor:
         """Mean over ranks of a small tensor of metrics (loss / SSIM logging, validation loss that

@@ -87,14 +87,23 @@ def make_loader(ds, indices, batch_size, workers, shuffle, seed):
                                        prefetch_factor=2 if workers > 0 else None, drop_last=False)
 
 
+def agree_on_seed(seed, world, device=None):
+    """Every rank must split train/val and shard the training set with the SAME permutation.  The reference's
+    ``--seed`` default is random (train.py:529) and is drawn independently in every torchrun rank: rank 0's value
+    wins (broadcast), an explicit --seed is the same on every rank anyway."""
+    if world <= 1:
+        return seed
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
 def train(args):
     global _RANK
     world = int(os.environ.get("WORLD_SIZE", "1"))
     _RANK = rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     setup_logging(args.log_dir)
-    torch.manual_seed(args.seed)
-    random.seed(args.seed)
     os.makedirs(args.checkpoint_dir, exist_ok=True)
     os.makedirs(os.path.join(args.checkpoint_dir, "samples"), exist_ok=True)
     if args.cpu or not torch.cuda.is_available():
@@ -108,6 +117,9 @@ def train(args):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+    args.seed = agree_on_seed(args.seed, world, device)
+    torch.manual_seed(args.seed)
+    random.seed(args.seed)
     log_message(f"Using device: {device} ({torch.cuda.get_device_name(local_rank)}), world size {world}")
     if args.use_amp:
         log_message("Using bf16 MFMA compute (fp32 accumulate, statistics and master weights).")
@@ -162,8 +174,7 @@ def train(args):
         idx = [train_idx[i] for i in shard_indices(n_train, rank, world, epoch, True, args.seed)] if world > 1 \
             else train_idx
         loader = make_loader(dataset, idx, args.batch_size, args.num_workers, True, args.seed + epoch)
-        acc = torch.zeros(2, device=device)          # running sums stay on the device: no per-batch host sync
-        nb = 0
+        acc = torch.zeros(3, device=device)          # running sums stay on the device: no per-batch host sync
         for batch_idx, (low, high) in enumerate(loader):
             low, high = low.to(device, non_blocking=True), high.to(device, non_blocking=True)
             optimizer.zero_grad(set_to_none=True)
@@ -176,30 +187,31 @@ def train(args):
             with torch.no_grad():
                 acc[0] += loss.detach()
                 acc[1] += ssim_metric(output, high)
-            nb += 1
+                acc[2] += 1
             if batch_idx % max(10, len(loader) // 10) == 0:
                 log_message({"epoch": epoch, "batch": batch_idx, "total_batches": len(loader),
                              "loss": float(loss.item())}, "batch_update")
         if dp is not None:
-            acc = dp.average_scalars(acc)
-        train_loss, train_ssim = (acc / max(nb, 1)).tolist()
+            acc = dp.sum_scalars(acc)
+        train_loss, train_ssim = (acc[:2] / acc[2].clamp_min(1)).tolist()
 
         if val_loader is not None:
             model.eval()
-            vacc = torch.zeros(2, device=device)
-            nv = 0
+            vacc = torch.zeros(3, device=device)       # (sum of batch losses, sum of batch SSIMs, batches)
+            vis = None
             with torch.no_grad():
                 for low, high in val_loader:
                     low, high = low.to(device, non_blocking=True), high.to(device, non_blocking=True)
                     out = model(low)
                     vacc[0] += criterion(out, high)
                     vacc[1] += ssim_metric(out, high)
-                    nv += 1
+                    vacc[2] += 1
                     vis = (low, high, out)
-            vacc = vacc / max(nv, 1)
             if dp is not None:
-                vacc = dp.average_scalars(vacc)      # identical on all ranks -> identical scheduler decisions
-            val_loss, val_ssim = vacc.tolist()
+                # (sum, count) pairs reduced, divided once: uneven / empty rank shards do not bias the mean, and the
+                # result is identical on all ranks -> identical scheduler / early-stopping decisions
+                vacc = dp.sum_scalars(vacc)
+            val_loss, val_ssim = (vacc[:2] / vacc[2].clamp_min(1)).tolist()
             prev_lr = optimizer.param_groups[0]["lr"]
             scheduler.step(val_loss)
             cur_lr = optimizer.param_groups[0]["lr"]
@@ -225,7 +237,7 @@ def train(args):
             if val_loss != "N/A":
                 writer.add_scalar("Loss/val", val_loss, epoch)
                 writer.add_scalar("SSIM/val", val_ssim, epoch)
-        if rank == 0 and val_loss != "N/A" and epoch % vis_frequency == 0:
+        if rank == 0 and val_loss != "N/A" and vis is not None and epoch % vis_frequency == 0:
             save_example_images(*vis, epoch, os.path.join(args.checkpoint_dir, "samples"))
         if val_loss != "N/A" and patience_counter >= args.patience:
             log_message(f"Early stopping triggered after {epoch + 1} epochs")

@@ -99,23 +99,29 @@ def test_loss_and_gradients_fp32(golden_dir, case, ssim_weight):
     _report(f"grads fp32 {case} ssim_w={ssim_weight}: loss err {abs(loss.item() - float(ref_loss)):.2e}, worst grad rel err {worst:.2e}")
 
 
-def test_gradients_bf16_close(golden_dir):
-    f, n, h, w, seed = 16, 2, 32, 32, 1
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gradients_bf16_close(golden_dir, seed):
+    """bf16 path vs the fp32 oracle.  Gate: cosine >= 0.95 and |norm ratio - 1| <= 0.10, widened per parameter by what
+    the CPU emulation of the same bf16 storage points (oracle/bf16_emul.py) shows for that parameter: gradients that
+    are strongly cancelling sums (1-channel stem conv, scalar alpha / output bias) move by 5-50 % under the FORWARD
+    roundings alone, either way depending on the seed (profiles/r02_bf16_grad_attribution.txt: the r01 deficits
+    0.83 / 0.90 / 0.91 are this, the backward storage points contribute < 0.5 %)."""
+    from oracle.bf16_emul import cos_ratio, emulated_grads
+    f, n, h, w = 16, 2, 32, 32
     sd = formula_state_dict(f, seed)
     low, high = make_pair(n, h, w, seed)
     _, ref_loss, ref_grads = loss_and_grads(sd, low, high, 0.4)
+    emu, _ = emulated_grads(sd, low, high, 0.4)
     m = _model(f, seed, torch.bfloat16).train()
     loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(m(low.cuda()), high.cuda())
     loss.backward()
     assert abs(loss.item() - float(ref_loss)) <= 5e-3 * float(ref_loss)
     for k, p in m.named_parameters():
-        r = ref_grads[k].flatten().double()
-        gq = p.grad.cpu().flatten().double()
-        cos = float((gq * r).sum() / (gq.norm() * r.norm()).clamp_min(1e-30))
-        ratio = float(gq.norm() / r.norm().clamp_min(1e-30))
-        _report(f"grads bf16 {k}: cosine {cos:.4f} norm ratio {ratio:.3f}")
-        assert cos >= 0.95, f"{k}: cosine {cos:.4f}"
-        assert abs(ratio - 1.0) <= 0.25, f"{k}: norm ratio {ratio:.3f}"
+        cos, ratio = cos_ratio(p.grad.cpu(), ref_grads[k])
+        ecos, eratio = cos_ratio(emu[k], ref_grads[k])
+        _report(f"grads bf16 seed {seed} {k}: cosine {cos:.4f} norm ratio {ratio:.3f} (emulated: {ecos:.4f} / {eratio:.3f})")
+        assert cos >= min(0.95, ecos - 0.03), f"{k}: cosine {cos:.4f} (emulated {ecos:.4f})"
+        assert abs(ratio - 1.0) <= 0.10 + abs(eratio - 1.0), f"{k}: norm ratio {ratio:.3f} (emulated {eratio:.3f})"
 
 
 def test_ssim_and_combined_loss_match_reference_golden(golden_dir):

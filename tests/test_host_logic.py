@@ -167,6 +167,39 @@ expect = torch.arange(m.flat_grads.numel(), dtype=torch.float32) * 1e-6 * sum(r 
 assert torch.allclose(m.flat_grads, expect, rtol=1e-6), (m.flat_grads - expect).abs().max()
 avg = dp.average_scalars(torch.tensor([float(rank), 2.0]))
 assert torch.allclose(avg, torch.tensor([(world - 1) / 2.0, 2.0]))
+# (sum, count) reduction: rank r contributes r+1 batches of loss 1.0 each -> the mean is 1.0 whatever the shard sizes
+tot = dp.sum_scalars(torch.tensor([float(rank + 1) * 1.0, float(rank + 1)]))
+assert abs(float(tot[0] / tot[1]) - 1.0) < 1e-7 and float(tot[1]) == sum(r + 1 for r in range(world))
+# gradient accumulation contract: a non-fresh backward on top of reduced gradients must raise, no_sync() must not reduce
+dp._on_backward_start(True)
+dp.finish_gradients()
+try:
+    dp._on_backward_start(False)
+    raise SystemExit("accumulating onto all-reduced gradients did not raise")
+except RuntimeError as e:
+    assert "no_sync" in str(e)
+dp._on_backward_start(True)
+before = m.flat_grads.clone()
+with dp.no_sync():
+    for name in order:
+        m.grad_ready_hook(name)
+    dp.finish_gradients()
+    dp._on_backward_start(False)              # accumulation under no_sync is legal
+assert torch.equal(m.flat_grads, before) and not dp.bucketer.handles
+# the reference's --seed default is random per process (train.py:529): every rank must end up with rank 0's draw
+sys.path.insert(0, os.path.join(os.environ["REPO"], "scripts"))
+import train as train_cli
+args = train_cli.parse_args(["--full_res_dir", "a", "--low_res_dir", "b"])
+if rank == 1:
+    args.seed += 1                             # make sure the ranks really disagree before the exchange
+seed = train_cli.agree_on_seed(args.seed, world)
+seeds = [None] * world
+dist.all_gather_object(seeds, seed)
+assert len(set(seeds)) == 1, seeds
+perm = torch.randperm(37, generator=torch.Generator().manual_seed(seed)).tolist()
+perms = [None] * world
+dist.all_gather_object(perms, perm)
+assert perms[0] == perms[1]
 dist.destroy_process_group()
 print("OK", rank)
 """
@@ -181,6 +214,26 @@ def test_data_parallel_bucketed_allreduce_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("OK") == 2
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` typed directly: the parent never touches the GPU, it spawns torch.distributed.run."""
+    sys.path.insert(0, REPO)
+    import bench
+    cmd = bench.rank_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert 1024 < bench.free_port() < 65536
+    src = open(os.path.join(REPO, "bench.py")).read()
+    head = src[:src.index("def main():")]
+    assert "\nimport torch" not in head, "bench.py must not import torch before it knows it is a rank process"
+    # traffic provenance: a stale / missing PMC table must read as None, never as old numbers
+    table, prov = bench.pmc_traffic()
+    assert (table is None) == (not prov.startswith("rocprofv3")), prov
+    assert len(bench.csrc_sha16()) == 16
 
 
 def test_evaluation_metrics_and_interpolation_baselines():

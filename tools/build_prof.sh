@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 python -m mri_superresolution_amd.build
 mkdir -p build/prof
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DMRISR_PHASE_TIMING -fno-slp-vectorize $PROF_FLAGS \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DMRISR_PHASE_TIMING -DMRISR_TUNING -fno-slp-vectorize $PROF_FLAGS \
     -c mri_superresolution_amd/csrc/conv_fwd.hip -o build/prof/conv_fwd.o
 objs=$(ls build/mrisr/*.o | grep -v conv_fwd.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o mri_superresolution_amd/libmrisr_${PROF_NAME:-prof}.so build/prof/conv_fwd.o $objs

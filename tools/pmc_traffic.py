@@ -7,13 +7,20 @@ reports exactly half of the bytes of wide (16 B/lane) coalesced reads -> doubled
 stores and dword float atomics.  Both counters come from the L2's memory-side request counters (Infinity-Cache hits
 are counted, not excluded), i.e. this is traffic leaving L2, an upper bound on DRAM traffic.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json] [steps]
+
+`steps` = optimiser steps the profiled command ran (warm-up + timed + instrumented): gives hbm_bytes_per_step.
+The output is stamped with the hash of the kernel sources (bench.py:csrc_sha16); bench.py reports traffic only while
+that hash still matches.
 """
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def demangle_conv(name):
@@ -53,6 +60,7 @@ def collect(path, counter):
 def main():
     fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     ft, fc = collect(fetch_csv, "FETCH_SIZE")
     wt, wc = collect(write_csv, "WRITE_SIZE")
     kernels = {}
@@ -62,7 +70,11 @@ def main():
         wr = wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)
         kernels[k] = {"launches": fc.get(k, wc.get(k, 0)), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                       "hbm_bytes_per_launch": round(rd + wr)}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), "
+    from bench import csrc_sha16
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kernels.values())
+    json.dump({"csrc_sha16": csrc_sha16(), "steps_profiled": steps,
+               "hbm_bytes_per_step": round(total / steps) if steps else None,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), "
                          "FETCH_SIZE x2 (gfx950 wide-read correction), KB->bytes x1024",
                "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:25]:
