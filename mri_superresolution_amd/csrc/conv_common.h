@@ -32,8 +32,14 @@ static inline size_t conv_stage_bytes() {
     return 0;
 #endif
 }
-static inline bool conv_weights_stationary(int nchunks, size_t wimg) {
-    return nchunks * wimg + 2 * conv_halo_bytes() + (64 + 128) * sizeof(float) + conv_stage_bytes() <= 159 * 1024;   // + bias, affine tables, staging
+// LDS-DMA halo variant (sources stored as-is: input gradients, materialised activations, VGG): four halo buffers (two
+// per half, double-buffered) of 340 rows x 64 B - rows are 64 B with the 16-B chunk position XOR-swizzled by
+// (row >> 2) & 3 like the weight image (an LDS-DMA piece is 1 KiB of consecutive LDS bytes, so rows cannot be padded)
+constexpr int kDmaHaloRows = 340;     // max over the tile shapes: 10 x 34 (8x32 and 32x8 tiles), 18 x 18 = 324
+constexpr int kDmaHaloBytes = kDmaHaloRows * 64;
+static inline size_t conv_halo_total(bool dma) { return dma ? 4 * (size_t)kDmaHaloBytes : 2 * conv_halo_bytes(); }
+static inline bool conv_weights_stationary(int nchunks, size_t wimg, bool dma = false) {
+    return nchunks * wimg + conv_halo_total(dma) + (64 + 128) * sizeof(float) + conv_stage_bytes() <= 159 * 1024;   // + bias, affine tables, staging
 }
 // wgrad kernel variant: 0 = generic, 1 / 2 / 4 = FAST with that k-step interleave (bf16 3x3 plain loader, 8x32 tiles,
 // every channel block of the launch holding the same number of 32x32 fragment pairs)

@@ -77,8 +77,22 @@ __device__ unsigned long long g_phase_cycles[8][12];
 #define PT_WAIT_LOADS()
 #endif
 
-template <typename T, int BN, int SPATIAL, int KS, bool WS, int EPI>
+// One 16-byte-per-lane LDS-DMA (global_load_lds_dwordx4): the active lanes' 16 bytes go to LDS bytes
+// [lds_dst + 16 * lane, + 16) with no register staging; counted on vmcnt like a load.  Inline asm: hipcc's own waitcnt
+// bookkeeping does not see it (in-order retirement makes that safe: an unknown operation can only make the compiler's
+// counted waits longer), completion waits are explicit.  M0 carries the LDS base and is restored.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
+// DMA = true (plain loader, every source MRISR_SRC_RAW): the halo tile goes global -> LDS by LDS-DMA, double-buffered
+// per half; the vector phase of a tick then holds no loads, no transform and no LDS commit - only the DMA issue of the
+// next item, the zero fill of conv-padding slots and the epilogue.
+template <typename T, int BN, int SPATIAL, int KS, bool WS, int EPI, bool DMA = false>
 __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvParams p_in) {
+    static_assert(!DMA || SPATIAL == MRISR_SP_NONE, "the LDS-DMA halo path is the plain loader's");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams p = pin_params(p_in);
     constexpr int NTAPS = KS * KS;
@@ -95,7 +109,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     const int TW = 1 << p.tw_log2, TH = p.th;
     const int hw = TW + 2 * PAD, hh = TH + 2 * PAD;
     const int npix_halo = hw * hh;
-    constexpr int halo_bytes = kMaxHaloIter * 64 * kHaloRowBytes;   // full slots: commits are unpredicated
+    // register-staged: one tile of full slots per half (commits are unpredicated); DMA: two 340-row buffers per half
+    constexpr int halo_bytes = DMA ? 2 * kDmaHaloBytes : kMaxHaloIter * 64 * kHaloRowBytes;
     char* lds_halo = smem + half * halo_bytes;
     // streamed weights: TWO images shared by both halves - item c (the halves run the same (tile, chunk) sequence one
     // tick apart) uses image c & 1; each half loads and writes the image of every other item (see the schedule below)
@@ -164,6 +179,21 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         xb[mi] = halo_off((pl >> p.tw_log2) * hw + (pl & (TW - 1)), lh);
     }
     int wb = lds_off(lr, lh);     // k-step 1 = this XOR 32; taps / fragments are constant offsets
+    // DMA halo image: row r = halo pixel, 64 B, chunk c at position c ^ ((r >> 2) & 3) - the tap shift changes the
+    // swizzle per lane, so the 2 x NTAPS fragment offsets are tile-independent per-lane constants (k-step 1 = XOR 32)
+    int xa[2][DMA ? NTAPS : 1];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int pl = wave * 64 + mi * 32 + lr;
+            const int r0 = (pl >> p.tw_log2) * hw + (pl & (TW - 1));
+#pragma unroll
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                const int r = r0 + (tap / KS) * hw + (tap % KS);
+                xa[mi][tap] = r * 64 + ((lh ^ ((r >> 2) & 3)) << 4);
+            }
+        }
+    }
 
     // tile-independent halo slot coordinates of this thread: slot i = halo pixel (t>>2) + 64 i
     int hyx[kMaxHaloIter];
@@ -277,8 +307,45 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         }
     };
 #endif
+    // LDS-DMA of a work item's halo tile into buffer `buf` of this half.  Slot i of thread t = halo pixel (t >> 2) + 64 i,
+    // chunk position t & 3 - i.e. wave w's instruction i fills the 16 rows 64 i + 16 w .. + 15 of the image, lane l at
+    // byte 16 l of that 1 KiB piece - so the lane fetches the LOGICAL chunk (t & 3) ^ ((row >> 2) & 3) of its pixel
+    // (row >> 2 = (t >> 4) mod 4 for every i).  Addresses as in the plain loader below (scalar image base + two 24-bit
+    // mads).  Slots that must read as zero (conv padding, channels beyond Cin) are not fetched but zero-filled.
+    auto issue_dma = [&](int n, int kc, int ty0, int tx0, int buf) {
+        if (DBG(p) & 4) return;
+        const int ns = __builtin_amdgcn_readfirstlane(n), kcs = __builtin_amdgcn_readfirstlane(kc);
+        const int ty0s = __builtin_amdgcn_readfirstlane(ty0), tx0s = __builtin_amdgcn_readfirstlane(tx0);
+        const int bufs = __builtin_amdgcn_readfirstlane(buf), w0 = __builtin_amdgcn_readfirstlane(wave);
+        const int c0 = kcs * (kRowBytes / (int)sizeof(T)) + ((t & 3) ^ ((t >> 4) & 3)) * VEC;
+        const bool w1 = p.nsrc > 1 && c0 >= p.src[0].C;        // per lane: a chunk may straddle the two concat sources
+        const int cs = w1 ? c0 - p.src[0].C : c0;
+        const int Cs = w1 ? p.src[1].C : p.src[0].C;
+        const bool cok = cs < Cs;
+        const char* b0 = image_base(p.src[0].ptr, ns, p.src[0].img_bytes);
+        const char* b1 = image_base(p.src[1].ptr, ns, p.src[1].img_bytes);
+        const char* base = w1 ? b1 : b0;
+        const unsigned Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W;
+        const int ys0 = ty0s - PAD - (w1 ? p.src[1].off_y : p.src[0].off_y);
+        const int xs0 = tx0s - PAD - (w1 ? p.src[1].off_x : p.src[0].off_x);
+        const unsigned C2 = Cs * (unsigned)sizeof(T), cbytes = (cok ? cs : 0) * (unsigned)sizeof(T);
+        char* hb = lds_halo + bufs * kDmaHaloBytes;
+        const unsigned hb_s = (unsigned)(size_t)(__attribute__((address_space(3))) char*)hb;
+        u32x4 zv = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            // (slots beyond the halo have hyx = -1: x = xs0 + 0xffff is out of range for every W < 32768)
+            const unsigned y = ys0 + (hyx[i] >> 16), x = xs0 + (hyx[i] & 0xffff);
+            const bool ok = cok & (y < Hs) & (x < Ws);
+            const unsigned off = mad_u24(mad_u24(y, Ws, x), C2, cbytes);
+            const int row0 = 64 * i + 16 * w0;                 // wave-uniform: first row of this instruction's piece
+            if (ok) lds_dma16(base + off, (unsigned)__builtin_amdgcn_readfirstlane((int)(hb_s + row0 * 64)));
+            else if (i < 4 || hyx[i] >= 0) *reinterpret_cast<u32x4*>(hb + row0 * 64 + lane * 16) = zv;
+        }
+    };
     auto issue = [&](int n, int kc, int ty0, int tx0) {
         if (DBG(p) & 4) return;
+        if constexpr (DMA) return;
         if constexpr (NH == 1) {
             // Plain loader.  Everything is derived per item from wave-uniform scalars (image, tile origin, chunk: SALU
             // after the readfirstlanes) and the packed halo-slot coordinates: no per-tile geometry registers, no 64-bit
@@ -374,6 +441,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // transform + store the prefetched item into LDS (gather modes: stage synchronously)
     auto commit = [&](int n, int kc, int ty0, int tx0) {
         if (DBG(p) & 2) return;
+        if constexpr (DMA) return;
         if constexpr (NH == 1) {
             // straight-line: y = x*sc+sh, act = max(y, slope*y), unpredicated 16-B LDS
             // store of every slot; the slots that must read as zero (conv padding, channels beyond Cin) are then
@@ -651,7 +719,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     if (nitems > 0) {
         decode(cur_tile, cur_n, cur_ty0, cur_tx0);
         set_geom(cur_n, cur_ty0, cur_tx0);
-        issue(cur_n, 0, cur_ty0, cur_tx0);
+        if constexpr (DMA) issue_dma(cur_n, 0, cur_ty0, cur_tx0, 0);
+        else issue(cur_n, 0, cur_ty0, cur_tx0);
     }
 #ifdef MRISR_DMA_WEIGHTS
     if constexpr (!WS) {
@@ -665,7 +734,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     }
 #endif
     if constexpr (NH == 1) {
-        if (wave == 0 && nitems > 0) lds_aff[lane] = pf.aff;     // first item's table; later ones at the end of a matrix phase
+        if constexpr (!DMA) {
+            if (wave == 0 && nitems > 0) lds_aff[lane] = pf.aff;     // first item's table; later ones at the end of a matrix phase
+        }
         __syncthreads();
     }
     // static priority for the younger half (waves 4-7 lose the VALU arbitration to the older half of their SIMD on every
@@ -681,7 +752,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         if (phase >= 0 && (phase & 1) == 0) {
             // ------------------------------------------------ vector phase
 #ifdef MRISR_DMA_WEIGHTS
-            if constexpr (!WS) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): half 0's image DMA of the last matrix phase has landed
+            // vmcnt(0): half 0's image DMA of the last matrix phase has landed; DMA halo: so has item c's tile, issued in
+            // this half's previous vector phase (one tick pair ago) - the barrier at the end of this tick publishes both
+            if constexpr (!WS || DMA) __builtin_amdgcn_s_waitcnt(0x0f70);
 #else
             if constexpr (!WS) {
                 if (!(c & 1) && c + half < nitems0) store_weights(c + half);
@@ -707,7 +780,12 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     }
                 }
                 PT_MARK(2)
-                issue(nxt_n, nxt_kc, nxt_ty0, nxt_tx0);     // unconditional: after the last item this re-loads valid addresses and is never committed
+                if constexpr (DMA) {
+                    // buffer (c + 1) & 1 was last read by this half's matrix phase c - 1, i.e. in the previous tick
+                    if (c + 1 < nitems) issue_dma(nxt_n, nxt_kc, nxt_ty0, nxt_tx0, (c + 1) & 1);
+                } else {
+                    issue(nxt_n, nxt_kc, nxt_ty0, nxt_tx0);     // unconditional: after the last item this re-loads valid addresses and is never committed
+                }
                 PT_MARK(3)
             }
             if (ep_pending) {
@@ -744,7 +822,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
             const char* wl = lds_w + (size_t)(WS ? cur_kc : (c & 1)) * (WIMG_VECS * 16);
             // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
             // out of the persistent loop into 36 VGPRs
-            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
+            if constexpr (!DMA) asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
+            const char* hbuf = lds_halo + (DMA ? (c & 1) * kDmaHaloBytes : 0);
 #ifndef MRISR_NO_PIPE_MMA
             if (!(DBG(p) & 8)) {
                 // 2 * NTAPS steps of (2 pixel fragments, NF weight fragments, 2 * NF MFMAs), software-pipelined by one step
@@ -758,8 +837,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     const int tap = st >> 1, ks = st & 1;
                     const int tapoff = ((tap / KS) * hw + (tap % KS)) * kHaloRowBytes;
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        xf[buf][mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
+                    for (int mi = 0; mi < 2; ++mi) {
+                        if constexpr (DMA) xf[buf][mi] = *reinterpret_cast<const frag_t*>(hbuf + (xa[mi][tap] ^ (32 * ks)));
+                        else xf[buf][mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
+                    }
 #pragma unroll
                     for (int ni = 0; ni < NF; ++ni)
                         wf[buf][ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
@@ -789,8 +870,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     for (int ks = 0; ks < 2; ++ks) {
                         frag_t xf[2], wf[NF];
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
-                            xf[mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
+                        for (int mi = 0; mi < 2; ++mi) {
+                            if constexpr (DMA) xf[mi] = *reinterpret_cast<const frag_t*>(hbuf + (xa[mi][tap] ^ (32 * ks)));
+                            else xf[mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
+                        }
 #pragma unroll
                         for (int ni = 0; ni < NF; ++ni)
                             wf[ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
@@ -807,7 +890,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 ep_n = cur_n; ep_ty0 = cur_ty0; ep_tx0 = cur_tx0;
             }
             cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
-            if constexpr (NH == 1) {
+            if constexpr (NH == 1 && !DMA) {
                 // affine table of the item this half commits in the next tick (loaded by its last issue)
                 if (wave == 0) lds_aff[lane] = pf.aff;
             }
@@ -1014,15 +1097,23 @@ int num_cus() {
 
 int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s);
 
-template <typename T, int BN, int SPATIAL, int KS>
-static int launch_conv(ConvParams& p, hipStream_t s) {
-    const int TW = 1 << p.tw_log2, pad = KS / 2;
-    (void)TW; (void)pad;
-    const size_t halo_bytes = conv_halo_bytes();
+// every source stored as-is and a plain (single / concat) loader: the halo tile can go global -> LDS by LDS-DMA
+static bool conv_dma_halo(const ConvParams& p, int spatial) {
+#ifdef MRISR_NO_DMA_HALO
+    return false;
+#endif
+    if (spatial != MRISR_SP_NONE || p.combine == MRISR_COMBINE_BLEND) return false;
+    for (int s = 0; s < p.nsrc; ++s)
+        if (p.src[s].mode != MRISR_SRC_RAW) return false;
+    return true;
+}
+
+template <typename T, int BN, int SPATIAL, int KS, bool DMA>
+static int launch_conv_v(ConvParams& p, hipStream_t s) {
     const size_t wimg = (size_t)KS * KS * BN * kRowBytes;
-    // weights-stationary when every cin chunk fits next to the two halo tiles
-    p.ws = conv_weights_stationary(p.nchunks, wimg) ? 1 : 0;
-    const size_t lds = 2 * halo_bytes + (p.ws ? p.nchunks : 2) * wimg + (BN + 128) * sizeof(float) + conv_stage_bytes();
+    // weights-stationary when every cin chunk fits next to the halo tiles
+    p.ws = conv_weights_stationary(p.nchunks, wimg, DMA) ? 1 : 0;
+    const size_t lds = conv_halo_total(DMA) + (p.ws ? p.nchunks : 2) * wimg + (BN + 128) * sizeof(float) + conv_stage_bytes();
     p.ntiles = p.N * p.tiles_y * p.tiles_x;
     int per_cb = num_cus() / p.ncb;                     // persistent workgroups per cout block, one per CU
     if (per_cb < 1) per_cb = 1;
@@ -1035,36 +1126,36 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
     double* stats = p.stats;
     const bool stats_sep = stats && ((p.Cout / p.groups) & 3);
     if (stats_sep) p.stats = nullptr;
-    constexpr bool kPS = (SPATIAL == MRISR_SP_NONE && KS == 3);   // pixel-shuffle epilogue: plain 3x3 convs only
+    constexpr bool kPS = (SPATIAL == MRISR_SP_NONE && KS == 3);   // pixel-shuffle / mask epilogues: plain 3x3 convs only
     static std::once_flag attr_once;   // per instantiation
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if constexpr (kPS) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
     });
     if (p.out_mode == MRISR_OUT_PIXEL_SHUFFLE2) {
         if constexpr (kPS) {
-            if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1>), dim3(grid), dim3(kFwdThreads), lds, s, p);
-            else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+            if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 1, DMA>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 1, DMA>), dim3(grid), dim3(kFwdThreads), lds, s, p);
         } else {
             MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: pixel-shuffle epilogue needs a 3x3 conv with a plain source");
         }
     } else if (p.mask) {
         if constexpr (kPS) {
-            if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask>), dim3(grid), dim3(kFwdThreads), lds, s, p);
-            else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+            if (p.ws) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, kEpiMask, DMA>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, kEpiMask, DMA>), dim3(grid), dim3(kFwdThreads), lds, s, p);
         } else {
             MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask epilogue needs a 3x3 conv with a plain source");
         }
     } else if (p.ws) {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, true, 0, DMA>), dim3(grid), dim3(kFwdThreads), lds, s, p);
     } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0>), dim3(grid), dim3(kFwdThreads), lds, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, SPATIAL, KS, false, 0, DMA>), dim3(grid), dim3(kFwdThreads), lds, s, p);
     }
     MRISR_CHECK_LAUNCH("conv_forward");
     if (stats_sep) {
@@ -1072,6 +1163,14 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
         return launch_gn_stats(TypeTraits<T>::kDtype, p.out, stats, p.N, (ps ? 4 : 1) * p.H * p.W, ps ? p.Cout / 4 : p.Cout, p.groups, s);
     }
     return MRISR_OK;
+}
+
+template <typename T, int BN, int SPATIAL, int KS>
+static int launch_conv(ConvParams& p, hipStream_t s) {
+    if constexpr (SPATIAL == MRISR_SP_NONE) {
+        if (conv_dma_halo(p, SPATIAL)) return launch_conv_v<T, BN, SPATIAL, KS, true>(p, s);
+    }
+    return launch_conv_v<T, BN, SPATIAL, KS, false>(p, s);
 }
 
 template <typename T, int BN>
@@ -1104,9 +1203,10 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     } else {
         const int BN = conv_choose_bn(d->Cout);
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
-        const int ws = conv_weights_stationary(p.nchunks, wimg) ? 1 : 0;
-        snprintf(out, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", t, BN, loader, d->ksize, ws,
-                 d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 ? 1 : (d->relu_mask ? kEpiMask : 0));
+        const bool dma = conv_dma_halo(p, d->src[0].spatial);
+        const int ws = conv_weights_stationary(p.nchunks, wimg, dma) ? 1 : 0;
+        snprintf(out, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d>", t, BN, loader, d->ksize, ws,
+                 d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 ? 1 : (d->relu_mask ? kEpiMask : 0), dma ? 1 : 0);
     }
     return MRISR_OK;
 }

@@ -104,10 +104,12 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
     constexpr int VEC = Vec16<T>::N;
     __shared__ float lds[256 * VEC * 2];
     const int t = threadIdx.x, n = blockIdx.y;
-    const int nvec = p.C / VEC, ppb = 256 / nvec;
+    // blockIdx.z = channel slice of 256 vectors (wide fp32 nodes: C / VEC > 256); one slice everywhere else
+    const int cz = blockIdx.z * 256 * VEC;
+    const int nvec = min(256, p.C / VEC - (int)blockIdx.z * 256), ppb = 256 / nvec;
     const int cv = t % nvec, pl = t / nvec;
     const bool active = pl < ppb;
-    const int c = cv * VEC;
+    const int c = cz + cv * VEC;
     const int HW = p.H * p.W;
     const int gs = p.C / p.groups;
 
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
         const int cvj = j / VEC, e = j - cvj * VEC;
         float s = 0.f;
         for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
-        atomic_add_f32(&p.red[((size_t)n * p.C + cvj * VEC + e) * 2 + which], s);
+        atomic_add_f32(&p.red[((size_t)n * p.C + cz + cvj * VEC + e) * 2 + which], s);
     }
 }
 
@@ -249,8 +251,9 @@ __global__ __launch_bounds__(256) void act_bwd_pool_window_kernel(const ActBwdPa
     constexpr int VEC = Vec16<T>::N;
     __shared__ float lds[APPLY ? 2 : 256 * VEC * 2];
     const int t = threadIdx.x, n = blockIdx.y;
-    const int nvec = p.C / VEC, ppb = 256 / nvec;
-    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    const int cz = blockIdx.z * 256 * VEC;        // channel slice, see act_bwd_reduce_kernel
+    const int nvec = min(256, p.C / VEC - (int)blockIdx.z * 256), ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cz + cv * VEC;
     const bool active = pl < ppb;
     const int Hp = p.H / 2, Wp = p.W / 2, HWp = Hp * Wp, W = p.W;
     const int kp = p.cons[0].spatial == MRISR_SP_POOL2 ? 0 : 1, ko = 1 - kp;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void act_bwd_pool_window_kernel(const ActBwdPa
             const int cvj = j / VEC, e = j - cvj * VEC;
             float s = 0.f;
             for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
-            atomic_add_f32(&p.red[((size_t)n * p.C + cvj * VEC + e) * 2 + which], s);
+            atomic_add_f32(&p.red[((size_t)n * p.C + cz + cvj * VEC + e) * 2 + which], s);
         }
     }
 }
@@ -384,14 +387,15 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C;
     int rc = fill_act_bwd_params(p, dtype, nconsumers, consumers, blend_alpha, H, W, C, "act_bwd_apply_fused");
     if (rc) return rc;
-    if (C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
+    // channel slices of 256 vectors (blockIdx.z); the pixel blocking follows the widest slice
+    const int nslice = ceil_div(C / vec, 256), nvs = nslice > 1 ? 256 : C / vec;
     hipStream_t s = (hipStream_t)stream;
     if (window) {
-        const int nvw = C / vec, ppbw = 256 / nvw, HWp = (H / 2) * (W / 2);
+        const int nvw = nvs, ppbw = 256 / nvw, HWp = (H / 2) * (W / 2);
         int ppw = ppbw * 16;
         if (ppw > HWp) ppw = ceil_div(HWp, ppbw) * ppbw;
         p.pix_per_block = ppw;
-        dim3 gridw(ceil_div(HWp, ppw), N);
+        dim3 gridw(ceil_div(HWp, ppw), N, nslice);
         if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, true><<<gridw, 256, 0, s>>>(p, coef, (bf16_t*)dx);
         else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, true><<<gridw, 256, 0, s>>>(p, coef, (float*)dx);
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
@@ -401,11 +405,11 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     bool same = true;
     for (int k = 0; k < nconsumers; ++k)
         same = same && consumers[k].H == H && consumers[k].W == W && consumers[k].off_y == 0 && consumers[k].off_x == 0;
-    const int nvec = C / vec, ppb = 256 / nvec, HW = H * W;
+    const int nvec = nvs, ppb = 256 / nvec, HW = H * W;
     int ppblk = ppb * 32;
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     p.pix_per_block = ppblk;
-    dim3 grid(ceil_div(HW, ppblk), N);
+    dim3 grid(ceil_div(HW, ppblk), N, nslice);
     if (dtype == MRISR_BF16) {
         if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
         else act_bwd_apply_fused_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
@@ -424,7 +428,7 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     if (!x || !scale || !shift || !meanrstd || !red || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: null pointer");
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: %d consumers", nconsumers);
     const int vec = dtype == MRISR_BF16 ? 8 : 4;
-    if (C % vec || C / vec > 256 || groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: C %d", C);
+    if (C % vec || groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: C %d", C);
     ActBwdParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.scale = scale; p.shift = shift; p.meanrstd = meanrstd; p.blend_alpha = blend_alpha; p.g = g; p.red = red;
@@ -440,18 +444,19 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
         if (c.spatial == MRISR_SP_POOL2 && (c.H != H / 2 || c.W != W / 2)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d POOL2 extent", k);
         p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode};
     }
-    const int nvec = C / vec, ppb = 256 / nvec;
+    const int nslice = ceil_div(C / vec, 256);     // channel slices of 256 vectors (blockIdx.z)
+    const int nvec = nslice > 1 ? 256 : C / vec, ppb = 256 / nvec;
     int ppblk = ppb * 16;      // (32 measured slower: fewer blocks, longer tail)
     const int HW = H * W;
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     p.pix_per_block = ppblk;
-    dim3 grid(ceil_div(HW, ppblk), N);
+    dim3 grid(ceil_div(HW, ppblk), N, nslice);
     if (!g && !alpha_slots && act_bwd_window_ok(nconsumers, consumers, H, W)) {     // pass 1 of the window pair
         const int HWp = (H / 2) * (W / 2);
         int ppw = ppb * 16;
         if (ppw > HWp) ppw = ceil_div(HWp, ppb) * ppb;
         p.pix_per_block = ppw;
-        dim3 gridw(ceil_div(HWp, ppw), N);
+        dim3 gridw(ceil_div(HWp, ppw), N, nslice);
         hipStream_t sw = (hipStream_t)stream;
         if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (bf16_t*)nullptr);
         else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, false><<<gridw, 256, 0, sw>>>(p, nullptr, (float*)nullptr);
@@ -589,8 +594,8 @@ __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdPa
                                                                   T* __restrict__ dx) {
     constexpr int VEC = Vec16<T>::N;
     const int t = threadIdx.x, n = blockIdx.y;
-    const int nvec = p.C / VEC, ppb = 256 / nvec;
-    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    const int nvec = min(256, p.C / VEC - (int)blockIdx.z * 256), ppb = 256 / nvec;     // blockIdx.z: channel slice
+    const int cv = t % nvec, pl = t / nvec, c = blockIdx.z * 256 * VEC + cv * VEC;
     if (pl >= ppb) return;
     const size_t NC = (size_t)p.N * p.C;
     const int HW = p.H * p.W;

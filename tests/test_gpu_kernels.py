@@ -69,6 +69,38 @@ def test_conv_streamed_weight_images(dt, shape, ks):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", ["concat_pad", "multitile", "narrow_image", "cin_tail"])
+def test_conv_dma_halo_raw_sources(dt, case):
+    """Sources stored as-is take the LDS-DMA halo path (conv_igemm_kernel<..., DMA = 1>): two raw concat sources whose
+    channel boundary falls inside a 64-byte chunk with the second one padded (unet_model.py:86-90), long persistent tile
+    ranges with image changes inside a workgroup's range, tiles narrower / shorter than 8 x 32, Cin that is not a multiple
+    of the chunk (zero-filled channel tail)."""
+    if case == "concat_pad":
+        n, c0, c1, cout, h, w = 2, 24, 16, 64, 25, 35
+        a, b = rnd(n, c0, h, w, seed=31), rnd(n, c1, 24, 33, seed=32)
+        srcs = [U.SrcSpec(a), U.SrcSpec(b, off=(0, 1))]
+        cin = c0 + c1
+    else:
+        n, cin, cout, h, w = {"multitile": (3, 64, 64, 72, 100), "narrow_image": (2, 32, 32, 40, 12),
+                              "cin_tail": (1, 40, 96, 17, 33)}[case]
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=33))]
+    wt = rnd(cout, cin, 3, 3, seed=34, scale=0.1)
+    out, stats = U.conv_forward(dt, srcs, wt, h, w, 3)
+    ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w), U.rounded(wt, dt), padding=1)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    o = ref.view(n, 8, cout // 8, h, w).double()
+    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-3 * o.abs().max().item())
+    assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    # and it IS the DMA variant that ran
+    import ctypes as C
+    keep = []
+    d = U.make_desc(dt, srcs, h, w, cin, cout, 3, keep=keep)
+    name = C.create_string_buffer(96)
+    L.call("mrisr_conv_variant", C.byref(d), 0, name, 96)
+    assert name.value.decode().endswith(",1>"), name.value
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_conv1x1_and_bias(dt):
     n, cin, cout, h, w = 2, 64, 32, 20, 36
     x, wt, b = rnd(n, cin, h, w, seed=3), rnd(cout, cin, 1, 1, seed=4, scale=0.2), rnd(cout, seed=5)

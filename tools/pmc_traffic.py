@@ -24,10 +24,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def demangle_conv(name):
-    m = re.match(r"_Z17conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)EEv10ConvParams", name)
+    m = re.match(r"_Z17conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])EEv10ConvParams", name)
     if m:
         t = "bf16" if m.group(1) == "DF16b" else "f32"
-        return f"conv_igemm_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)}>"
+        return f"conv_igemm_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)},{m.group(7)}>"
     m = re.match(r"_Z17conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv10ConvParams", name)
     if m:
         t = "bf16" if m.group(1) == "DF16b" else "f32"
