@@ -53,6 +53,7 @@ struct Prefetch {
     float slope;                                  // NH == 1: activation as max(y, slope*y): 0.2 NORM, 1 RAW, 0 RELU
 };
 
+struct NoPace {};                   // run_mma without DMA pacing (antiphase schedule)
 constexpr int kFwdThreads = 512;    // two 4-wave halves working in antiphase
 constexpr int kLoaderBlend = 3;     // template-only loader kind: sigmoid(alpha)-blend of two sources
 constexpr int kEpiMask = 2;         // template-only epilogue kind: plain store gated by relu_mask > 0 (VGG dgrad)
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
         for (int v = threadIdx.x; v < p.nchunks * WIMG_VECS; v += kFwdThreads) reinterpret_cast<u32x4*>(lds_w)[v] = gload<u32x4>(wsrc + v);
     }
     const bool has_br = p.bias != nullptr || p.relu_out != 0;      // block-uniform: epilogue with bias / ReLU
+    const bool has_stats = p.stats != nullptr;
     const bool all_raw = p.src[0].mode == MRISR_SRC_RAW && (p.nsrc < 2 || p.src[1].mode == MRISR_SRC_RAW);   // block-uniform
     if (threadIdx.x < BN) lds_bias[threadIdx.x] = (p.bias && bn0 + (int)threadIdx.x < p.Cout) ? gload<float>(p.bias + bn0 + threadIdx.x) : 0.f;
 
@@ -285,17 +287,19 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // Measured against the register-staged variant (each half loading / storing every other image): same results, 204
     // instead of 244 VGPRs, streamed-weights kernel 108.5 -> 107.7 us inside the step (-DMRISR_NO_DMA_WEIGHTS builds that
     // variant).
-    auto dma_weights = [&](int kc, int item) {
+    // (NWV = 4: issued by the four waves of half 0 - the antiphase schedule; NWV = 8: by all eight waves - symmetric one)
+    auto dma_weights = [&](int kc, int item, auto nwv_tag) {
+        constexpr int NWV = decltype(nwv_tag)::value;
         if (DBG(p) & (4 | 256)) return;
         if constexpr (!WS) {
             constexpr int NPIECE = WIMG_VECS * 16 / 1024;
             const int kcs = __builtin_amdgcn_readfirstlane(kc), its = __builtin_amdgcn_readfirstlane(item);
-            const int w0 = __builtin_amdgcn_readfirstlane(wave);
+            const int w0 = __builtin_amdgcn_readfirstlane(NWV == 8 ? (int)(threadIdx.x >> 6) : wave);
             const char* src = wbase + (size_t)kcs * (WIMG_VECS * 16) + lane * 16;
             const unsigned dst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_w + (unsigned)(its & 1) * (WIMG_VECS * 16);
 #pragma unroll
-            for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
-                const int piece = w0 + 4 * j;
+            for (int j = 0; j < (NPIECE + NWV - 1) / NWV; ++j) {
+                const int piece = w0 + NWV * j;
                 if (piece < NPIECE) {
                     unsigned keep;
                     const char* g = src + piece * 1024;
@@ -591,10 +595,12 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         v[j] = acc[ni][mi][4 * q + j];
                         acc[ni][mi][4 * q + j] = 0.f;
                     }
-                    const float qs = (v[0] + v[1]) + (v[2] + v[3]);
-                    const float qq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                    st_s[ni][q] = fmaf(pvf, qs, st_s[ni][q]);
-                    st_ss[ni][q] = fmaf(pvf, qq, st_ss[ni][q]);
+                    if (has_stats) {   // block-uniform: input-gradient and VGG launches carry no GroupNorm statistics
+                        const float qs = (v[0] + v[1]) + (v[2] + v[3]);
+                        const float qq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                        st_s[ni][q] = fmaf(pvf, qs, st_s[ni][q]);
+                        st_ss[ni][q] = fmaf(pvf, qq, st_ss[ni][q]);
+                    }
                     if constexpr (sizeof(T) == 2) {   // bf16: packed, stored after the lane exchange below
                         union { bf16x4 b; u32x2 u; } cv;
                         cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
@@ -703,127 +709,42 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
 #endif
         }
     };
-    // ---- schedule: commit phase c at tick 2c + half, MFMA phase c at tick 2c + 1 + half
-    int cur_tile = tile0, cur_kc = 0, cur_n = 0, cur_ty0 = 0, cur_tx0 = 0;       // item c
-    int nxt_tile = tile0, nxt_kc = 0, nxt_n = 0, nxt_ty0 = 0, nxt_tx0 = 0;       // item c + 1
-    int ep_n = 0, ep_ty0 = 0, ep_tx0 = 0;
-    bool ep_pending = false;
-    // Streamed weights, shared between the halves: half 0 writes the image of the even items (at its own commit of that
-    // item), half 1 the image of the odd items (one item ahead, at its commit of the even item before): an image is
-    // written in a tick in which nobody reads it (item c: half 0 reads in tick 2c+1, half 1 in tick 2c+2; image c & 1 is
-    // rewritten for item c+2 in tick 2c+3 or 2c+4), and every half loads / stores 9 vectors per thread for every OTHER
-    // item instead of for every item (measured: the 9 weight ds_write_b128 were half of the commit time).  The duty runs
-    // on half 0's item count, so half 1 keeps serving half 0's last tile when it has one tile less.
-    const int nitems0 = nh0 * p.nchunks;
-    int wkc = half;            // cin chunk of this half's next weight target (items half, half + 2, ...; nchunks >= 3 here)
-    if (nitems > 0) {
-        decode(cur_tile, cur_n, cur_ty0, cur_tx0);
-        set_geom(cur_n, cur_ty0, cur_tx0);
-        if constexpr (DMA) issue_dma(cur_n, 0, cur_ty0, cur_tx0, 0);
-        else issue(cur_n, 0, cur_ty0, cur_tx0);
-    }
-#ifdef MRISR_DMA_WEIGHTS
-    if constexpr (!WS) {
-        if (half == 0 && nitems0 > 0) dma_weights(0, 0);
-        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the image is in LDS before the barrier below
-        if constexpr (NH != 1) __syncthreads();
-    }
-#else
-    if constexpr (!WS) {
-        if (half < nitems0) issue_weights(wkc);
-    }
-#endif
-    if constexpr (NH == 1) {
-        if constexpr (!DMA) {
-            if (wave == 0 && nitems > 0) lds_aff[lane] = pf.aff;     // first item's table; later ones at the end of a matrix phase
-        }
-        __syncthreads();
-    }
-    // static priority for the younger half (waves 4-7 lose the VALU arbitration to the older half of their SIMD on every
-    // tick: measured 26 k vs 31 k cycles for the same commit work); a provably uniform condition, s_setprio ignores EXEC
-#ifndef MRISR_NO_STATIC_PRIO
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
-    PT_DECL
-    for (int tick = 0; tick < nticks; ++tick) {
-        const int phase = tick - half;
-        const int c = phase >> 1;
-        PT_MARK(8)
-        if (phase >= 0 && (phase & 1) == 0) {
-            // ------------------------------------------------ vector phase
-#ifdef MRISR_DMA_WEIGHTS
-            // vmcnt(0): half 0's image DMA of the last matrix phase has landed; DMA halo: so has item c's tile, issued in
-            // this half's previous vector phase (one tick pair ago) - the barrier at the end of this tick publishes both
-            if constexpr (!WS || DMA) __builtin_amdgcn_s_waitcnt(0x0f70);
-#else
-            if constexpr (!WS) {
-                if (!(c & 1) && c + half < nitems0) store_weights(c + half);
-            }
-#endif
-            // Order: commit item c (its loads were issued one full tick pair ago) -> issue the loads of item c+1
-            // right away (the prefetch registers are free again) -> only then the epilogue of the tile that finished
-            // in the previous matrix phase.  The loads thus have the rest of this phase plus the whole matrix phase
-            // to land; issued at the start of the matrix phase they had half of that and the commit stalled on
-            // vmcnt (measured: 20-40 us per launch).
-            if (c < nitems) {
-                PT_WAIT_LOADS();
-                PT_MARK(0)
-                commit(cur_n, cur_kc, cur_ty0, cur_tx0);
-                PT_MARK(1)
-                nxt_tile = cur_tile; nxt_kc = cur_kc + 1; nxt_n = cur_n; nxt_ty0 = cur_ty0; nxt_tx0 = cur_tx0;
-                if (nxt_kc == p.nchunks) {
-                    nxt_kc = 0;
-                    nxt_tile = cur_tile + 1;
-                    if (nxt_tile < tile1) {
-                        decode(nxt_tile, nxt_n, nxt_ty0, nxt_tx0);
-                        set_geom(nxt_n, nxt_ty0, nxt_tx0);
-                    }
-                }
-                PT_MARK(2)
-                if constexpr (DMA) {
-                    // buffer (c + 1) & 1 was last read by this half's matrix phase c - 1, i.e. in the previous tick
-                    if (c + 1 < nitems) issue_dma(nxt_n, nxt_kc, nxt_ty0, nxt_tx0, (c + 1) & 1);
-                } else {
-                    issue(nxt_n, nxt_kc, nxt_ty0, nxt_tx0);     // unconditional: after the last item this re-loads valid addresses and is never committed
-                }
-                PT_MARK(3)
-            }
-            if (ep_pending) {
-                epilogue(ep_n, ep_ty0, ep_tx0);
-                PT_MARK(4)
-                if (p.stats && (c >= nitems || cur_n != ep_n)) flush_stats(ep_n);
-                ep_pending = false;
-                PT_MARK(9)
-            }
-        } else if (phase >= 0) {
-          // ------------------------------------------------ matrix phase
-#ifdef MRISR_DMA_WEIGHTS
-          if constexpr (!WS) {
-              // half 0, every item: image (c + 1) & 1 (last read two ticks ago) <- weights of item c + 1; it lands during
-              // this matrix phase and is waited for at the start of this half's next vector phase
-              if (half == 0 && c < nitems && c + 1 < nitems0) dma_weights(nxt_kc, c + 1);
-          }
-#else
-          if constexpr (!WS) {
-              // odd item index: load the image this half stores in its next vector phase (target item c + 1 + half)
-              if ((c & 1) && c + 1 + half < nitems0) {
-                  wkc += 2;
-                  if (wkc >= p.nchunks) wkc -= p.nchunks;
-                  issue_weights(wkc);
-              } else {
-                  // not loaded on this path: an empty asm "defines" the registers so that they are not live across the
-                  // rest of the loop (36 VGPRs)
+    // ---- the MFMA block of one work item: halo tile at `hbuf`, weight image at `wl`
+    auto run_mma = [&](const char* hbuf, const char* wl, auto&& pace) {
+            constexpr bool PACED = !std::is_same<std::decay_t<decltype(pace)>, NoPace>::value;
+            if constexpr (PACED) {
+                // Symmetric schedule: the same one-step-ahead pipeline, with the LDS-DMA instructions of the NEXT item
+                // dealt out one per step (`pace(st)`) instead of issued as a burst: a burst of ~10 DMAs per wave fills
+                // the CU's memory queue and stalls each issuing wave for ~2-3 k cycles (measured: 1700-2700 cycles of
+                // issue per item and wave = as long as its MFMA block), during which it issues no MFMA either; paced,
+                // the SIMD's other wave keeps the matrix pipe busy.  sched_barrier(0) pins the per-step order
+                // (reads of step s+1 / DMA -> MFMAs of step s): inline asm is invisible to sched_group_barrier.
+                constexpr int NSTEP = 2 * NTAPS;
+                frag_t xf[2][2], wf[2][NF];
+                auto load_step = [&](int st, int buf) {
+                    const int tap = st >> 1, ks = st & 1;
 #pragma unroll
-                  for (int j = 0; j < NW; ++j) asm volatile("" : "=v"(pf.w[j].v));
-              }
-          }
-#endif
-          if (c < nitems) {
-            const char* wl = lds_w + (size_t)(WS ? cur_kc : (c & 1)) * (WIMG_VECS * 16);
-            // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
-            // out of the persistent loop into 36 VGPRs
-            if constexpr (!DMA) asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
-            const char* hbuf = lds_halo + (DMA ? (c & 1) * kDmaHaloBytes : 0);
+                    for (int mi = 0; mi < 2; ++mi) xf[buf][mi] = *reinterpret_cast<const frag_t*>(hbuf + (xa[mi][tap] ^ (32 * ks)));
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+                        wf[buf][ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
+                };
+                load_step(0, 0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    if (st + 1 < NSTEP) load_step(st + 1, (st + 1) & 1);
+                    pace(st);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(DBG(p) & 8)) {
+#pragma unroll
+                        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+                            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mma<T>::run(wf[st & 1][ni], xf[st & 1][mi], acc[ni][mi]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
 #ifndef MRISR_NO_PIPE_MMA
             if (!(DBG(p) & 8)) {
                 // 2 * NTAPS steps of (2 pixel fragments, NF weight fragments, 2 * NF MFMAs), software-pipelined by one step
@@ -837,10 +758,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     const int tap = st >> 1, ks = st & 1;
                     const int tapoff = ((tap / KS) * hw + (tap % KS)) * kHaloRowBytes;
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        if constexpr (DMA) xf[buf][mi] = *reinterpret_cast<const frag_t*>(hbuf + (xa[mi][tap] ^ (32 * ks)));
-                        else xf[buf][mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
-                    }
+                    for (int mi = 0; mi < 2; ++mi)
+                        xf[buf][mi] = *reinterpret_cast<const frag_t*>(hbuf + xb[mi] + tapoff + 32 * ks);
 #pragma unroll
                     for (int ni = 0; ni < NF; ++ni)
                         wf[buf][ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
@@ -870,10 +789,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     for (int ks = 0; ks < 2; ++ks) {
                         frag_t xf[2], wf[NF];
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi) {
-                            if constexpr (DMA) xf[mi] = *reinterpret_cast<const frag_t*>(hbuf + (xa[mi][tap] ^ (32 * ks)));
-                            else xf[mi] = *reinterpret_cast<const frag_t*>(lds_halo + xb[mi] + tapoff + 32 * ks);
-                        }
+                        for (int mi = 0; mi < 2; ++mi)
+                            xf[mi] = *reinterpret_cast<const frag_t*>(hbuf + xb[mi] + tapoff + 32 * ks);
 #pragma unroll
                         for (int ni = 0; ni < NF; ++ni)
                             wf[ni] = *reinterpret_cast<const frag_t*>(wl + ((wb ^ (32 * ks)) + (tap * BN + ni * 32) * kRowBytes));
@@ -885,12 +802,261 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                 }
             }
 #endif
+    };
+    // ---- paced LDS-DMA (symmetric schedule): plan_dma computes what issue_dma / dma_weights would issue for an item,
+    // pace_dma(step) issues ONE of those instructions (or the zero fill of a padding slot)
+    struct DmaPlan {
+        unsigned off[NSLOT];      // byte offset of slot i's 16 bytes from `base`
+        unsigned okmask, zmask;   // bit i: slot i is fetched / slot i is zero-filled (conv padding, channels beyond Cin)
+        const char* base;         // this lane's source image
+        char* hb;                 // destination halo buffer
+        const char* wsrc;         // next weight image in global memory + lane * 16
+        unsigned wdst;            // LDS address of the weight image to fill
+        bool do_halo, do_w;
+    };
+    auto plan_dma = [&](DmaPlan& pl, int n, int kc, int ty0, int tx0, int buf, int item, bool do_halo, bool do_w) {
+        const int ns = __builtin_amdgcn_readfirstlane(n), kcs = __builtin_amdgcn_readfirstlane(kc);
+        const int ty0s = __builtin_amdgcn_readfirstlane(ty0), tx0s = __builtin_amdgcn_readfirstlane(tx0);
+        const int bufs = __builtin_amdgcn_readfirstlane(buf), its = __builtin_amdgcn_readfirstlane(item);
+        const int c0 = kcs * (kRowBytes / (int)sizeof(T)) + ((t & 3) ^ ((t >> 4) & 3)) * VEC;
+        const bool w1 = p.nsrc > 1 && c0 >= p.src[0].C;
+        const int cs = w1 ? c0 - p.src[0].C : c0;
+        const int Cs = w1 ? p.src[1].C : p.src[0].C;
+        const bool cok = cs < Cs;
+        const char* b0 = image_base(p.src[0].ptr, ns, p.src[0].img_bytes);
+        const char* b1 = image_base(p.src[1].ptr, ns, p.src[1].img_bytes);
+        pl.base = w1 ? b1 : b0;
+        const unsigned Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W;
+        const int ys0 = ty0s - PAD - (w1 ? p.src[1].off_y : p.src[0].off_y);
+        const int xs0 = tx0s - PAD - (w1 ? p.src[1].off_x : p.src[0].off_x);
+        const unsigned C2 = Cs * (unsigned)sizeof(T), cbytes = (cok ? cs : 0) * (unsigned)sizeof(T);
+        pl.hb = lds_halo + bufs * kDmaHaloBytes;
+        unsigned okm = 0, zm = 0;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const unsigned y = ys0 + (hyx[i] >> 16), x = xs0 + (hyx[i] & 0xffff);
+            const bool ok = cok & (y < Hs) & (x < Ws);
+            pl.off[i] = mad_u24(mad_u24(y, Ws, x), C2, cbytes);
+            okm |= (ok ? 1u : 0u) << i;
+            zm |= ((!ok && (i < 4 || hyx[i] >= 0)) ? 1u : 0u) << i;
+        }
+        pl.okmask = okm; pl.zmask = zm;
+        pl.do_halo = do_halo; pl.do_w = do_w;
+        pl.wsrc = wbase + (size_t)kcs * (WIMG_VECS * 16) + lane * 16;
+        pl.wdst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_w + (unsigned)(its & 1) * (WIMG_VECS * 16);
+    };
+    auto pace_dma = [&](const DmaPlan& pl, int st) {
+        if (DBG(p) & 4) return;
+        constexpr int NPIECE = WS ? 0 : WIMG_VECS * 16 / 1024, NWJ = (NPIECE + 7) / 8;
+        constexpr int PER = KS == 3 ? 1 : 8;           // operations per step (a 1x1 conv has only two steps)
+#pragma unroll
+        for (int k = st * PER; k < (st + 1) * PER; ++k) {
+            if ((k & 1) == 0) {
+                const int i = k >> 1;
+                if (i < NSLOT && pl.do_halo) {
+                    const int w0 = __builtin_amdgcn_readfirstlane(wave);
+                    const int row0 = 64 * i + 16 * w0;
+                    if ((pl.okmask >> i) & 1) {
+                        const unsigned hb_s = (unsigned)(size_t)(__attribute__((address_space(3))) char*)pl.hb;
+                        lds_dma16(pl.base + pl.off[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(hb_s + row0 * 64)));
+                    } else if ((pl.zmask >> i) & 1) {
+                        *reinterpret_cast<u32x4*>(pl.hb + row0 * 64 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+                    }
+                }
+            } else {
+                const int j = k >> 1;
+                if (j < NWJ && pl.do_w) {
+                    const int piece = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + 8 * j;
+                    if (piece < NPIECE) lds_dma16(pl.wsrc + piece * 1024, (unsigned)__builtin_amdgcn_readfirstlane((int)(pl.wdst + piece * 1024)));
+                }
+            }
+        }
+    };
+    // ---- DMA variant: SYMMETRIC schedule.  With the halo tile and the weight image both arriving by LDS-DMA a wave has
+    // almost no vector work left, so the antiphase roles are dropped: both halves run the same loop - wait for item c's
+    // DMAs, ONE workgroup barrier per item, issue the DMAs of item c + 1 into the other buffers, the 72 MFMAs of item c,
+    // and the epilogue after a tile's last chunk - and the two waves of a SIMD fill each other's LDS-wait / epilogue
+    // gaps on the matrix pipe.  Measured (profiles/r02_conv_dma_schedules.txt, 128 -> 128 at 128^2, batch 16): antiphase
+    // with DMA 82-88 us, symmetric with a DMA burst at the top of each item 80-85 us, symmetric with paced DMAs 80-82 us -
+    // the schedule hardly matters: the loop is power-limited (shader clock 1.55-1.65 GHz under this load), with the
+    // MFMA + LDS-read part alone at 58.6 us (81 % matrix-pipe occupancy) and the DMA path alone at 46 us.  The
+    // symmetric form is kept for DMA sources because it has ONE barrier per item and no role state.  Buffers: item c reads
+    // halo buffer c & 1 of its half and weight image c & 1; the DMAs for item c + 1 are issued after the barrier that
+    // every wave passes once its MFMAs of item c - 1 (the last readers of those buffers) are done.
+    if constexpr (DMA) {
+        int it_tile = tile0, it_kc = 0, it_n = 0, it_ty0 = 0, it_tx0 = 0;
+        const int nitems_wg = nh0 * p.nchunks;         // half 0 never has fewer tiles than half 1
+        if (nitems > 0) {
+            decode(it_tile, it_n, it_ty0, it_tx0);
+            issue_dma(it_n, 0, it_ty0, it_tx0, 0);
+        }
+        if constexpr (!WS) {
+            if (nitems_wg > 0) dma_weights(0, 0, std::integral_constant<int, 8>{});
+        }
+        PT_DECL
+        for (int c = 0; c < nitems_wg; ++c) {
+            PT_MARK(8)
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's pieces of item c (and older stores) have landed
+            PT_MARK(0)
+            __syncthreads();
+            PT_MARK(5)
+            int nx_kc = it_kc + 1, nx_tile = it_tile, nx_n = it_n, nx_ty0 = it_ty0, nx_tx0 = it_tx0;
+            if (nx_kc == p.nchunks) {
+                nx_kc = 0;
+                nx_tile = it_tile + 1;
+                if (nx_tile < tile1) decode(nx_tile, nx_n, nx_ty0, nx_tx0);
+            }
+            PT_MARK(2)
+            // plan of the next item's DMAs (addresses and validity of this thread's halo slots, this wave's weight
+            // pieces); they are issued one per MFMA step by `pace`
+            DmaPlan plan;
+            plan_dma(plan, nx_n, nx_kc, nx_ty0, nx_tx0, (c + 1) & 1, c + 1, c + 1 < nitems, c + 1 < nitems_wg);
+            PT_MARK(3)
+            if (c < nitems) {
+                asm volatile("" : "+v"(wb));     // (see the antiphase schedule: keeps the 36 weight tap addresses out of VGPRs)
+                run_mma(lds_halo + (c & 1) * kDmaHaloBytes, lds_w + (size_t)(WS ? it_kc : (c & 1)) * (WIMG_VECS * 16),
+                        [&](int st) { pace_dma(plan, st); });
+                PT_MARK(6)
+                if (it_kc == p.nchunks - 1) {
+                    epilogue(it_n, it_ty0, it_tx0);
+                    PT_MARK(4)
+                    if (p.stats && (c + 1 >= nitems || nx_n != it_n)) flush_stats(it_n);
+                    PT_MARK(9)
+                }
+            } else {
+                // this half has run out of tiles but still owes its share of the next weight image
+#pragma unroll
+                for (int st = 0; st < 2 * NTAPS; ++st) pace_dma(plan, st);
+            }
+            it_kc = nx_kc; it_tile = nx_tile; it_n = nx_n; it_ty0 = nx_ty0; it_tx0 = nx_tx0;
+        }
+#ifdef MRISR_PHASE_TIMING
+        if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+            pt_acc[10] = __builtin_amdgcn_s_memrealtime() - pt_r0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) atomicAdd(&g_phase_cycles[threadIdx.x >> 6][k], pt_acc[k]);
+            if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[0][11], 1ull);
+        }
+#endif
+        return;
+    }
+    // ---- schedule: commit phase c at tick 2c + half, MFMA phase c at tick 2c + 1 + half
+    int cur_tile = tile0, cur_kc = 0, cur_n = 0, cur_ty0 = 0, cur_tx0 = 0;       // item c
+    int nxt_tile = tile0, nxt_kc = 0, nxt_n = 0, nxt_ty0 = 0, nxt_tx0 = 0;       // item c + 1
+    int ep_n = 0, ep_ty0 = 0, ep_tx0 = 0;
+    bool ep_pending = false;
+    // Streamed weights, shared between the halves: half 0 writes the image of the even items (at its own commit of that
+    // item), half 1 the image of the odd items (one item ahead, at its commit of the even item before): an image is
+    // written in a tick in which nobody reads it (item c: half 0 reads in tick 2c+1, half 1 in tick 2c+2; image c & 1 is
+    // rewritten for item c+2 in tick 2c+3 or 2c+4), and every half loads / stores 9 vectors per thread for every OTHER
+    // item instead of for every item (measured: the 9 weight ds_write_b128 were half of the commit time).  The duty runs
+    // on half 0's item count, so half 1 keeps serving half 0's last tile when it has one tile less.
+    const int nitems0 = nh0 * p.nchunks;
+    int wkc = half;            // cin chunk of this half's next weight target (items half, half + 2, ...; nchunks >= 3 here)
+    if (nitems > 0) {
+        decode(cur_tile, cur_n, cur_ty0, cur_tx0);
+        set_geom(cur_n, cur_ty0, cur_tx0);
+        issue(cur_n, 0, cur_ty0, cur_tx0);
+    }
+#ifdef MRISR_DMA_WEIGHTS
+    if constexpr (!WS) {
+        if (half == 0 && nitems0 > 0) dma_weights(0, 0, std::integral_constant<int, 4>{});
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the image is in LDS before the barrier below
+        if constexpr (NH != 1) __syncthreads();
+    }
+#else
+    if constexpr (!WS) {
+        if (half < nitems0) issue_weights(wkc);
+    }
+#endif
+    if constexpr (NH == 1) {
+        if (wave == 0 && nitems > 0) lds_aff[lane] = pf.aff;     // first item's table; later ones at the end of a matrix phase
+        __syncthreads();
+    }
+    // static priority for the younger half (waves 4-7 lose the VALU arbitration to the older half of their SIMD on every
+    // tick: measured 26 k vs 31 k cycles for the same commit work); a provably uniform condition, s_setprio ignores EXEC
+#ifndef MRISR_NO_STATIC_PRIO
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
+    PT_DECL
+    for (int tick = 0; tick < nticks; ++tick) {
+        const int phase = tick - half;
+        const int c = phase >> 1;
+        PT_MARK(8)
+        if (phase >= 0 && (phase & 1) == 0) {
+            // ------------------------------------------------ vector phase
+#ifdef MRISR_DMA_WEIGHTS
+            if constexpr (!WS) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): half 0's image DMA of the last matrix phase has landed
+#else
+            if constexpr (!WS) {
+                if (!(c & 1) && c + half < nitems0) store_weights(c + half);
+            }
+#endif
+            // Order: commit item c (its loads were issued one full tick pair ago) -> issue the loads of item c+1
+            // right away (the prefetch registers are free again) -> only then the epilogue of the tile that finished
+            // in the previous matrix phase.  The loads thus have the rest of this phase plus the whole matrix phase
+            // to land; issued at the start of the matrix phase they had half of that and the commit stalled on
+            // vmcnt (measured: 20-40 us per launch).
+            if (c < nitems) {
+                PT_WAIT_LOADS();
+                PT_MARK(0)
+                commit(cur_n, cur_kc, cur_ty0, cur_tx0);
+                PT_MARK(1)
+                nxt_tile = cur_tile; nxt_kc = cur_kc + 1; nxt_n = cur_n; nxt_ty0 = cur_ty0; nxt_tx0 = cur_tx0;
+                if (nxt_kc == p.nchunks) {
+                    nxt_kc = 0;
+                    nxt_tile = cur_tile + 1;
+                    if (nxt_tile < tile1) {
+                        decode(nxt_tile, nxt_n, nxt_ty0, nxt_tx0);
+                        set_geom(nxt_n, nxt_ty0, nxt_tx0);
+                    }
+                }
+                PT_MARK(2)
+                issue(nxt_n, nxt_kc, nxt_ty0, nxt_tx0);     // unconditional: after the last item this re-loads valid addresses and is never committed
+                PT_MARK(3)
+            }
+            if (ep_pending) {
+                epilogue(ep_n, ep_ty0, ep_tx0);
+                PT_MARK(4)
+                if (p.stats && (c >= nitems || cur_n != ep_n)) flush_stats(ep_n);
+                ep_pending = false;
+                PT_MARK(9)
+            }
+        } else if (phase >= 0) {
+          // ------------------------------------------------ matrix phase
+#ifdef MRISR_DMA_WEIGHTS
+          if constexpr (!WS) {
+              // half 0, every item: image (c + 1) & 1 (last read two ticks ago) <- weights of item c + 1; it lands during
+              // this matrix phase and is waited for at the start of this half's next vector phase
+              if (half == 0 && c < nitems && c + 1 < nitems0) dma_weights(nxt_kc, c + 1, std::integral_constant<int, 4>{});
+          }
+#else
+          if constexpr (!WS) {
+              // odd item index: load the image this half stores in its next vector phase (target item c + 1 + half)
+              if ((c & 1) && c + 1 + half < nitems0) {
+                  wkc += 2;
+                  if (wkc >= p.nchunks) wkc -= p.nchunks;
+                  issue_weights(wkc);
+              } else {
+                  // not loaded on this path: an empty asm "defines" the registers so that they are not live across the
+                  // rest of the loop (36 VGPRs)
+#pragma unroll
+                  for (int j = 0; j < NW; ++j) asm volatile("" : "=v"(pf.w[j].v));
+              }
+          }
+#endif
+          if (c < nitems) {
+            const char* wl = lds_w + (size_t)(WS ? cur_kc : (c & 1)) * (WIMG_VECS * 16);
+            // keep the bases opaque so the tap addresses are re-derived (one add each) instead of being hoisted
+            // out of the persistent loop into 36 VGPRs
+            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(wb));
+            run_mma(lds_halo, wl, NoPace{});
             if (cur_kc == p.nchunks - 1) {
                 ep_pending = true;
                 ep_n = cur_n; ep_ty0 = cur_ty0; ep_tx0 = cur_tx0;
             }
             cur_tile = nxt_tile; cur_kc = nxt_kc; cur_n = nxt_n; cur_ty0 = nxt_ty0; cur_tx0 = nxt_tx0;
-            if constexpr (NH == 1 && !DMA) {
+            if constexpr (NH == 1) {
                 // affine table of the item this half commits in the next tick (loaded by its last issue)
                 if (wave == 0) lds_aff[lane] = pf.aff;
             }
