@@ -29,7 +29,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 METRIC = "2D MRI slices/sec (train fwd+bwd) 256×256 U-Net; PSNR/SSIM vs ref"
 
 
@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="network input H=W (output is 2x)")
     ap.add_argument("--base-filters", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4, help="resolution levels (4 = the reference; 5 = BASELINE config 5, an extension)")
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "fp32"], default="bf16",
+                    help="fp16 = the reference's autocast dtype: f16 MFMA + torch.amp.GradScaler (loss scaling fused into Adam)")
     ap.add_argument("--ssim-weight", type=float, default=0.4)
     ap.add_argument("--perceptual-weight", type=float, default=0.0,
                     help="BASELINE.json configs[2]: + VGG19 perceptual term (random-init VGG19: no weights offline)")
@@ -169,7 +170,8 @@ def main():
     from mri_superresolution_amd.parallel import DataParallel
     from mri_superresolution_amd.utils.losses import SSIM, CombinedLoss
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    scaler = torch.amp.GradScaler("cuda") if args.dtype == "fp16" else None     # scripts/train.py:163
     torch.manual_seed(0)
     model = UNetSuperRes(1, 1, args.base_filters, depth=args.depth).to(dev).set_compute_dtype(dtype).train()
     opt = FusedAdam(model, lr=1e-4, weight_decay=1e-5)
@@ -186,7 +188,7 @@ def main():
     dp = None
     if world > 1 or force_dp:
         dp = DataParallel(model)
-        opt.grad_scale = 1.0 / world
+        opt.dp_grad_scale = 1.0 / world
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B, S = args.batch, args.size
     low = torch.rand(B, 1, S, S, generator=g).to(dev)
@@ -196,10 +198,17 @@ def main():
         opt.zero_grad(set_to_none=True)
         out = model(low)
         loss = crit(out, high)
-        loss.backward()
-        if dp is not None:
-            dp.finish_gradients()
-        opt.step()
+        if scaler is not None:              # scripts/train.py:309-311
+            scaler.scale(loss).backward()
+            if dp is not None:
+                dp.finish_gradients()
+            scaler.step(opt)
+            scaler.update()
+        else:
+            loss.backward()
+            if dp is not None:
+                dp.finish_gradients()
+            opt.step()
         with torch.no_grad():
             metric(out, high)
         return loss

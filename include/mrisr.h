@@ -40,6 +40,7 @@ extern "C" {
 
 #define MRISR_F32 0
 #define MRISR_BF16 1
+#define MRISR_F16 2  /* IEEE half storage + f16 MFMA (fp32 accumulate): torch.amp.autocast's dtype, scripts/train.py:303-306 */
 
 /* source transform applied while a convolution loads its input (never materialised) */
 #define MRISR_SRC_RAW 0      /* value as stored                                              */
@@ -257,6 +258,13 @@ int mrisr_feature_loss(int dtype, const void* a, const void* b, size_t n, int ki
 int mrisr_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale,
                     void* stream);
+/* The same update under torch.amp.GradScaler's device-side contract (fp16 autocast, scripts/train.py:303-311):
+ * gradients are multiplied by grad_mul / *loss_scale_device, the update is skipped when *found_inf_device != 0, and
+ * the bias-correction step count *step_device (int32 on the device, starts at 0) advances only when the update ran.
+ * loss_scale_device / found_inf_device may be NULL (= 1 / never).  No host read-back.                              */
+int mrisr_adam_step_amp(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int* step_device, float grad_mul,
+                        const float* loss_scale_device, const float* found_inf_device, void* stream);
 
 /* ---- layout helpers ----------------------------------------------------------------------- */
 int mrisr_cast(int src_dtype, const void* src, int dst_dtype, void* dst, size_t n, void* stream);

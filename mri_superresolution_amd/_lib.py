@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRISR_LIB") or os.path.join(_HERE, "libmrisr.so")   # MRISR_LIB: A/B builds (tuning)
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
 SP_NONE, SP_POOL2, SP_UP2 = 0, 1, 2
 COMBINE_CONCAT, COMBINE_BLEND = 0, 1
@@ -81,6 +81,7 @@ SIGNATURES = {
     "mrisr_maxpool2_backward": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_feature_loss": (_i, [_i, _vp, _vp, _sz, _i, _dp, _fp, _vp, _i, _vp]),
     "mrisr_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "mrisr_adam_step_amp": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _vp, _f, _fp, _fp, _vp]),
     "mrisr_cast": (_i, [_i, _vp, _i, _vp, _sz, _vp]),
 }
 

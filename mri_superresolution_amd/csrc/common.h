@@ -24,6 +24,10 @@ extern thread_local char g_mrisr_err[512];
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;      // IEEE half (MRISR_F16): the reference's autocast dtype (scripts/train.py:303-306), needs loss scaling
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -41,12 +45,21 @@ template <> struct TypeTraits<bf16_t> {
     static constexpr int kDtype = MRISR_BF16;
     static constexpr int kVec = 8;
 };
+template <> struct TypeTraits<f16_t> {
+    static constexpr int kDtype = MRISR_F16;
+    static constexpr int kVec = 8;
+};
+// elements per 16-byte vector of a storage dtype
+static inline int mrisr_vec(int dtype) { return dtype == MRISR_F32 ? 4 : 8; }
+static inline bool mrisr_dtype_ok(int dtype) { return dtype == MRISR_F32 || dtype == MRISR_BF16 || dtype == MRISR_F16; }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
 // A 16-byte register vector of T, with element access as float.
 template <typename T> struct Vec16;
@@ -65,6 +78,15 @@ template <> struct Vec16<bf16_t> {
     __device__ __forceinline__ void zero() {
         v = bf16x8{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f,
                    (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    }
+};
+template <> struct Vec16<f16_t> {
+    f16x8 v;
+    static constexpr int N = 8;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (f16_t)x; }
+    __device__ __forceinline__ void zero() {
+        v = f16x8{(f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f, (f16_t)0.f};
     }
 };
 template <typename T> __device__ __forceinline__ Vec16<T> load_vec16(const T* p) {

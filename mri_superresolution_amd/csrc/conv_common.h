@@ -44,13 +44,28 @@ static inline bool conv_weights_stationary(int nchunks, size_t wimg, bool dma = 
 // wgrad kernel variant: 0 = generic, 1 / 2 / 4 = FAST with that k-step interleave (bf16 3x3 plain loader, 8x32 tiles,
 // every channel block of the launch holding the same number of 32x32 fragment pairs)
 static inline int conv_wgrad_fast(int dtype, int loader, int ks, int tw_log2, int Cout, int Cin) {
-    if (dtype != MRISR_BF16 || loader != MRISR_SP_NONE || ks != 3 || tw_log2 != 5) return 0;
+    if (dtype == MRISR_F32 || loader != MRISR_SP_NONE || ks != 3 || tw_log2 != 5) return 0;
     const int nfo = Cout % 64 == 0 ? 2 : (Cout <= 32 ? 1 : 0), nfi = Cin % 64 == 0 ? 2 : (Cin <= 32 ? 1 : 0);
     if (!nfo || !nfi) return 0;
     return 4 / (nfo * nfi);
 }
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
-static inline int conv_bk(int dtype) { return dtype == MRISR_BF16 ? 32 : 16; }
+static inline int conv_bk(int dtype) { return dtype == MRISR_F32 ? 16 : 32; }
+
+// 8-element fragment of a 16-bit storage type and its 32x32x16 MFMA (fp32 accumulate)
+template <typename T> struct Frag16;
+template <> struct Frag16<bf16_t> {
+    typedef bf16x8 type;
+    static __device__ __forceinline__ f32x16 mma(type a, type b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Frag16<f16_t> {
+    typedef f16x8 type;
+    static __device__ __forceinline__ f32x16 mma(type a, type b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Frag16<float> {      // (placeholder so that dead 16-bit branches of fp32 instantiations still parse)
+    typedef bf16x8 type;
+    static __device__ __forceinline__ f32x16 mma(type, type, f32x16 c) { return c; }
+};
 
 struct SrcDev {
     const void* ptr;

@@ -26,6 +26,12 @@ template <> struct Mma<bf16_t> {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
+template <> struct Mma<f16_t> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     typedef f32x4 frag;
     // lane half h holds k = 4h..4h+3 of an 8-deep step: four exact-fp32 32x32x2 MFMAs, pairing
@@ -459,6 +465,31 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                     sc[e] = a4[0]; sc[e + 1] = a4[1]; sc[e + 2] = a4[2]; sc[e + 3] = a4[3];
                     sh[e] = b4[0]; sh[e + 1] = b4[1]; sh[e + 2] = b4[2]; sh[e + 3] = b4[3];
                 }
+                if constexpr (std::is_same<T, f16_t>::value) {
+                    // fp16 storage: the transform runs on packed halves - v_pk_fma_f16, v_pk_mul_f16, v_pk_max_f16 = 1.5
+                    // VALU instructions per element where the bf16 path needs ~4.5 (unpack, fma, mul, max, pack).  One
+                    // fp16 rounding per operation (the reference's autocast rounds once, after fp32 GroupNorm + LeakyReLU);
+                    // covered by the fp16 parity tolerances.
+                    f16x2 sc2[VEC / 2], sh2[VEC / 2];
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 2) {
+                        sc2[e / 2] = f16x2{(f16_t)sc[e], (f16_t)sc[e + 1]};
+                        sh2[e / 2] = f16x2{(f16_t)sh[e], (f16_t)sh[e + 1]};
+                    }
+                    const f16_t sl = (f16_t)pf.slope;
+                    const f16x2 sl2 = {sl, sl};
+#pragma unroll
+                    for (int i = 0; i < NSLOT; ++i) {
+#pragma unroll
+                        for (int e = 0; e < VEC; e += 2) {
+                            const f16x2 x2 = {pf.h[i][0].v[e], pf.h[i][0].v[e + 1]};
+                            const f16x2 y2 = x2 * sc2[e / 2] + sh2[e / 2];
+                            const f16x2 a2 = __builtin_elementwise_max(y2, y2 * sl2);
+                            pf.h[i][0].v[e] = a2[0];
+                            pf.h[i][0].v[e + 1] = a2[1];
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < NSLOT; ++i) {
                     // (scalar fp32 ops on purpose: measured with the per-wave phase profile, v_pk_fma_f32 / v_pk_mul_f32 in
@@ -469,6 +500,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         pf.h[i][0].set(e, fmaxf(y, pf.slope * y));
                     }
                     if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two slots' temporaries live at a time
+                }
                 }
             }
 #pragma unroll
@@ -602,8 +634,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                         st_ss[ni][q] = fmaf(pvf, qq, st_ss[ni][q]);
                     }
                     if constexpr (sizeof(T) == 2) {   // bf16: packed, stored after the lane exchange below
-                        union { bf16x4 b; u32x2 u; } cv;
-                        cv.b = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        typedef __attribute__((ext_vector_type(4))) T t4_t;     // bf16x4 / f16x4
+                        union { t4_t b; u32x2 u; } cv;
+                        cv.b = t4_t{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
                         packed[q] = cv.u;
                     } else if (pv && co < p.Cout && !(DBG(p) & 1)) {
                         if constexpr (!kPSE) {
@@ -645,8 +678,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
                                 const u32x4 m = gload<u32x4>(mbase + ob);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
-                                    const unsigned lo = __uint_as_float(m[k] << 16) > 0.f ? 0x0000ffffu : 0u;
-                                    const unsigned hi = __uint_as_float(m[k] & 0xffff0000u) > 0.f ? 0xffff0000u : 0u;
+                                    // (positive and non-zero <=> the 16 bits read as int16 are > 0, for bf16 and fp16 alike)
+                                    const unsigned lo = (short)(m[k] & 0xffffu) > 0 ? 0x0000ffffu : 0u;
+                                    const unsigned hi = ((int)m[k] >> 16) > 0 ? 0xffff0000u : 0u;
                                     o[k] &= (lo | hi);
                                 }
                             }
@@ -1161,6 +1195,8 @@ extern "C" int mrisr_pack_weights_batched(int dtype, const mrisr_pack_job* jobs_
     dim3 grid(256, njobs);     // small jobs leave their surplus blocks immediately; the largest image decides the time
     if (dtype == MRISR_BF16)
         pack_weights_batched_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const PackJobDev*)jobs_device);
+    else if (dtype == MRISR_F16)
+        pack_weights_batched_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const PackJobDev*)jobs_device);
     else if (dtype == MRISR_F32)
         pack_weights_batched_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const PackJobDev*)jobs_device);
     else
@@ -1187,6 +1223,9 @@ extern "C" int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, 
     if (dtype == MRISR_BF16)
         pack_weights_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)packed, Cout, Cin, ksize,
                                                                             transpose_flip, BN, ncb, nch);
+    else if (dtype == MRISR_F16)
+        pack_weights_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(w, (f16_t*)packed, Cout, Cin, ksize,
+                                                                           transpose_flip, BN, ncb, nch);
     else if (dtype == MRISR_F32)
         pack_weights_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(w, (float*)packed, Cout, Cin, ksize,
                                                                            transpose_flip, BN, ncb, nch);
@@ -1199,12 +1238,12 @@ extern "C" int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, 
 // ------------------------------------------------------------------------------------------------
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
     if (!d) MRISR_FAIL(MRISR_E_ARG, "%s: null descriptor", who);
-    if (d->dtype != MRISR_F32 && d->dtype != MRISR_BF16) MRISR_FAIL(MRISR_E_DTYPE, "%s: dtype %d", who, d->dtype);
+    if (!mrisr_dtype_ok(d->dtype)) MRISR_FAIL(MRISR_E_DTYPE, "%s: dtype %d", who, d->dtype);
     if (d->ksize != 1 && d->ksize != 3) MRISR_FAIL(MRISR_E_UNSUPPORTED, "%s: ksize %d", who, d->ksize);
     if (d->nsrc < 1 || d->nsrc > 2) MRISR_FAIL(MRISR_E_ARG, "%s: nsrc %d", who, d->nsrc);
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0)
         MRISR_FAIL(MRISR_E_SHAPE, "%s: bad dims N%d H%d W%d Cin%d Cout%d", who, d->N, d->H, d->W, d->Cin, d->Cout);
-    const int vec = d->dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(d->dtype);
     memset(&p, 0, sizeof(p));
     int csum = 0;
     for (int s = 0; s < d->nsrc; ++s) {
@@ -1223,7 +1262,7 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
             MRISR_FAIL(MRISR_E_SHAPE, "%s: pooled src%d %dx%d != conv input %dx%d", who, s, vh, vw, d->H, d->W);
         if ((size_t)d->N * a.H * a.W * a.C >= (1ull << 31)) MRISR_FAIL(MRISR_E_SHAPE, "%s: src%d exceeds 2^31 elements", who, s);
         // ranges of the 24-bit / 32-bit offset arithmetic of the plain loader
-        const size_t esz = d->dtype == MRISR_BF16 ? 2 : 4;
+        const size_t esz = d->dtype == MRISR_F32 ? 4 : 2;
         if ((size_t)a.H * a.W >= (1u << 24) || a.W >= 32768 || (size_t)a.C * esz >= (1u << 24) || (size_t)a.H * a.W * a.C * esz >= (1ull << 32))
             MRISR_FAIL(MRISR_E_SHAPE, "%s: src%d image %dx%dx%d exceeds the loader's offset range", who, s, a.H, a.W, a.C);
         p.src[s] = SrcDev{a.ptr, a.scale, a.shift, a.C, a.H, a.W, a.mode, a.off_y, a.off_x, (unsigned)((size_t)a.H * a.W * a.C * esz)};
@@ -1361,7 +1400,7 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     int rc = conv_fill_params(d, p, "conv_variant");
     if (rc) return rc;
     if (!out || n < 8) MRISR_FAIL(MRISR_E_ARG, "conv_variant: bad buffer");
-    const char* t = d->dtype == MRISR_BF16 ? "bf16" : "f32";
+    const char* t = d->dtype == MRISR_BF16 ? "bf16" : (d->dtype == MRISR_F16 ? "f16" : "f32");
     const int loader = d->combine == MRISR_COMBINE_BLEND ? 3 : d->src[0].spatial;
     if (wgrad) {
         snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d,%d>", t, loader, d->ksize,
@@ -1383,13 +1422,14 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     if (rc) return rc;
     if (!d->wpacked || !d->out) MRISR_FAIL(MRISR_E_ARG, "conv_forward: null weights/out");
     if (d->out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && (d->Cout % 16)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: pixel shuffle needs Cout%%16==0");
-    if (d->relu_mask && (d->out_mode != MRISR_OUT_PLAIN || d->Cout % (d->dtype == MRISR_BF16 ? 8 : 4)))
+    if (d->relu_mask && (d->out_mode != MRISR_OUT_PLAIN || d->Cout % (mrisr_vec(d->dtype))))
         MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask needs a plain output with Cout a multiple of the 16-byte vector");
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);
     const int sp = d->src[0].spatial;
     hipStream_t s = (hipStream_t)stream;
     const int BN = conv_choose_bn(d->Cout);
     if (d->dtype == MRISR_BF16) return BN == 64 ? dispatch_conv_sp<bf16_t, 64>(p, sp, d->ksize, s) : dispatch_conv_sp<bf16_t, 32>(p, sp, d->ksize, s);
+    if (d->dtype == MRISR_F16) return BN == 64 ? dispatch_conv_sp<f16_t, 64>(p, sp, d->ksize, s) : dispatch_conv_sp<f16_t, 32>(p, sp, d->ksize, s);
     return BN == 64 ? dispatch_conv_sp<float, 64>(p, sp, d->ksize, s) : dispatch_conv_sp<float, 32>(p, sp, d->ksize, s);
 }
 #endif  // MRISR_KERNEL_ONLY

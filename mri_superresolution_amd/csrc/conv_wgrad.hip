@@ -24,17 +24,19 @@
 
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_t> { static constexpr int BC = 64; };   // channels per 128-B row
+template <> struct WgTraits<f16_t> { static constexpr int BC = 64; };
 template <> struct WgTraits<float> { static constexpr int BC = 32; };
 
 constexpr int kWgThreads = 512;
 constexpr int kWgSlots = 6;          // halo pixels per thread: slot i = halo pixel (t>>3) + 64 i
 static_assert(kWgSlots == kMaxHaloIter, "HaloGeom holds kMaxHaloIter slots");
 
-__device__ __forceinline__ bf16x8 tr_read_frag(const char* base0, const char* base1) {
+template <typename T>
+__device__ __forceinline__ typename Frag16<T>::type tr_read_frag(const char* base0, const char* base1) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base0);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base1);
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    union { struct { s16x4 a, b; } s; typename Frag16<T>::type v; } u;
     u.s.a = lo;
     u.s.b = hi;
     return u.v;
@@ -299,16 +301,16 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             const int cls = (j + kw) & 3;      // scalar
             bb[j] = bufp + kw * 128 + (cls == 0 ? b_lane[0] : cls == 1 ? b_lane[1] : cls == 2 ? b_lane[2] : b_lane[3]);
         }
-        auto load_a = [&](int i) { return tr_read_frag(ab + i * KP * 2048, ab + i * KP * 2048 + 512); };
+        auto load_a = [&](int i) { return tr_read_frag<T>(ab + i * KP * 2048, ab + i * KP * 2048 + 512); };
         auto load_b = [&](int st) {
             const int ks = (st / NTG) * KP, tap = (TG ? NT0 : 0) + st % NTG;
             const int K = (ks >> 1) * HWC + (ks & 1) * 16 + (tap / KS) * HWC + (tap % KS);
             const char* b = bb[K & 3] + K * 128;
-            return tr_read_frag(b, b + 512);
+            return tr_read_frag<T>(b, b + 512);
         };
         // software pipeline: the B fragment of step s+2 and the A fragment of the next k-step are requested before
         // the MFMA of step s is issued, so two LDS reads are always in flight behind the matrix pipe
-        bf16x8 aq[2], bq[3];
+        typename Frag16<T>::type aq[2], bq[3];
         aq[0] = load_a(0);
         bq[0] = load_b(0);
         bq[1] = load_b(1);
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             if (st + 2 < NS) bq[(st + 2) % 3] = load_b(st + 2);
             if (j == 0 && (i + 1) * KP < 16) aq[(i + 1) & 1] = load_a(i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i & 1], bq[st % 3], acc[j], 0, 0, 0);
+            acc[j] = Frag16<T>::mma(aq[i & 1], bq[st % 3], acc[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
 #pragma unroll 2
             for (int ks = ks_lo; ks < ks_hi; ks += kparts) {
                 const int pk = ks * 16 + 8 * lh_o + gq;  // pixel (second read: +4)
-                const bf16x8 af = tr_read_frag(
+                const typename Frag16<T>::type af = tr_read_frag<T>(
                     lds_dy + lds_off128(pk, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1),
                     lds_dy + lds_off128(pk + 4, c_dy >> 5, (c_dy >> 3) & 3) + ((c_dy & 4) << 1));
                 const int hp = (pk >> p.tw_log2) * hw + (pk & (TW - 1));   // pk and pk+4 share the row
@@ -351,10 +353,10 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
                     const int tap = NTAPS == 1 ? 0 : (tg ? NT0 + j : j);
                     if (tap < NTAPS) {
                         const int h0 = hp + (tap / KS) * hw + (tap % KS);
-                        const bf16x8 bfr = tr_read_frag(
+                        const typename Frag16<T>::type bfr = tr_read_frag<T>(
                             lds_in + lds_off128(h0, c_b >> 5, (c_b >> 3) & 3) + ((c_b & 4) << 1),
                             lds_in + lds_off128(h0 + 4, c_b >> 5, (c_b >> 3) & 3) + ((c_b & 4) << 1));
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                        acc[j] = Frag16<T>::mma(af, bfr, acc[j]);
                     }
                 }
             }
@@ -502,7 +504,7 @@ static int dispatch_wgrad(ConvParams& p, int spatial, int ks, hipStream_t s) {
     }
     if (ks == 3) {
         if constexpr (sizeof(T) == 2) {
-            const int fast = conv_wgrad_fast(MRISR_BF16, spatial, 3, p.tw_log2, p.Cout, p.Cin);
+            const int fast = conv_wgrad_fast(TypeTraits<T>::kDtype, spatial, 3, p.tw_log2, p.Cout, p.Cin);
             if (fast == 1) return launch_wgrad<T, MRISR_SP_NONE, 3, 1>(p, s);
             if (fast == 2) return launch_wgrad<T, MRISR_SP_NONE, 3, 2>(p, s);
             if (fast == 4) return launch_wgrad<T, MRISR_SP_NONE, 3, 4>(p, s);
@@ -519,7 +521,7 @@ static int dispatch_wgrad(ConvParams& p, int spatial, int ks, hipStream_t s) {
 extern "C" size_t mrisr_conv_wgrad_workspace_floats(const mrisr_conv_desc* d) {
     ConvParams p;
     if (conv_fill_params(d, p, "conv_wgrad_workspace_floats")) return 0;
-    const int BC = d->dtype == MRISR_BF16 ? 64 : 32;
+    const int BC = d->dtype == MRISR_F32 ? 32 : 64;
     int nblk, ksplit;
     wgrad_grid(p, BC, nblk, ksplit);
     return (size_t)nblk * ksplit * 8 * ((d->ksize * d->ksize + 1) / 2) * 16 * 64;
@@ -531,7 +533,7 @@ extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float*
     int rc = conv_fill_params(d, p, "conv_wgrad");
     if (rc) return rc;
     if (!dy || !dw) MRISR_FAIL(MRISR_E_ARG, "conv_wgrad: null dy/dw");
-    const int vec = d->dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(d->dtype);
     if (d->Cout % vec) MRISR_FAIL(MRISR_E_SHAPE, "conv_wgrad: Cout %d not a multiple of %d", d->Cout, vec);
     p.dy = dy;
     p.dw = dw;
@@ -539,6 +541,7 @@ extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float*
     p_ws_floats = workspace ? workspace_floats : 0;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MRISR_BF16) return dispatch_wgrad<bf16_t>(p, d->src[0].spatial, d->ksize, s);
+    if (d->dtype == MRISR_F16) return dispatch_wgrad<f16_t>(p, d->src[0].spatial, d->ksize, s);
     return dispatch_wgrad<float>(p, d->src[0].spatial, d->ksize, s);
 }
 #endif  // MRISR_KERNEL_ONLY

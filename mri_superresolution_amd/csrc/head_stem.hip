@@ -91,7 +91,7 @@ static int stem_block_pixels(int W, int ppb, int& max_rows) {
 extern "C" int mrisr_stem_forward(int dtype, const float* x, const float* w, void* out, double* stats, int N, int H,
                                   int W, int Cout, int groups, void* stream) {
     if (!x || !w || !out) MRISR_FAIL(MRISR_E_ARG, "stem_forward: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (Cout % vec || Cout / vec > 256 || (stats && (groups <= 0 || Cout % groups))) MRISR_FAIL(MRISR_E_SHAPE, "stem_forward: Cout %d", Cout);
     const int ppb = 256 / (Cout / vec);
     int max_rows;
@@ -100,6 +100,7 @@ extern "C" int mrisr_stem_forward(int dtype, const float* x, const float* w, voi
     const size_t lds = (size_t)max_rows * W * sizeof(float) + (size_t)(groups > 0 ? groups : 1) * 2 * sizeof(double);
     if (lds > 64 * 1024) MRISR_FAIL(MRISR_E_UNSUPPORTED, "stem_forward: image width %d too large for the row cache", W);
     if (dtype == MRISR_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (bf16_t*)out, stats, H, W, Cout, groups, ppblk, max_rows);
+    else if (dtype == MRISR_F16) stem_fwd_kernel<f16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (f16_t*)out, stats, H, W, Cout, groups, ppblk, max_rows);
     else if (dtype == MRISR_F32) stem_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, w, (float*)out, stats, H, W, Cout, groups, ppblk, max_rows);
     else MRISR_FAIL(MRISR_E_DTYPE, "stem_forward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("stem_forward");
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 extern "C" int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float* dw, int N, int H, int W, int Cout,
                                 void* stream) {
     if (!x || !dy || !dw) MRISR_FAIL(MRISR_E_ARG, "stem_wgrad: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (Cout % vec || Cout / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "stem_wgrad: Cout %d", Cout);
     const int ppb = 256 / (Cout / vec);
     int max_rows;
@@ -173,6 +174,7 @@ extern "C" int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float
     const size_t lds = (size_t)max_rows * W * sizeof(float);
     if (lds > 48 * 1024) MRISR_FAIL(MRISR_E_UNSUPPORTED, "stem_wgrad: image width %d too large for the row cache", W);
     if (dtype == MRISR_BF16) stem_wgrad_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, (const bf16_t*)dy, dw, H, W, Cout, ppblk);
+    else if (dtype == MRISR_F16) stem_wgrad_kernel<f16_t><<<grid, 256, lds, (hipStream_t)stream>>>(x, (const f16_t*)dy, dw, H, W, Cout, ppblk);
     else if (dtype == MRISR_F32) stem_wgrad_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(x, (const float*)dy, dw, H, W, Cout, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "stem_wgrad: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("stem_wgrad");
@@ -209,11 +211,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 extern "C" int mrisr_head_forward(int dtype, const void* x, const float* scale, const float* shift, const float* w,
                                   const float* b, float* out, int N, int H, int W, int C, void* stream) {
     if (!x || !scale || !shift || !w || !b || !out) MRISR_FAIL(MRISR_E_ARG, "head_forward: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "head_forward: C %d", C);
     dim3 grid(ceil_div(H * W, 256), N);
     const size_t lds = 3 * C * sizeof(float);
     if (dtype == MRISR_BF16) head_fwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, w, b, out, H * W, C);
+    else if (dtype == MRISR_F16) head_fwd_kernel<f16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const f16_t*)x, scale, shift, w, b, out, H * W, C);
     else if (dtype == MRISR_F32) head_fwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)x, scale, shift, w, b, out, H * W, C);
     else MRISR_FAIL(MRISR_E_DTYPE, "head_forward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("head_forward");
@@ -276,12 +279,13 @@ extern "C" int mrisr_head_backward(int dtype, const void* x, const float* scale,
                                    const float* out, const float* dout, void* da, float* dw, float* db, int N, int H,
                                    int W, int C, void* stream) {
     if (!x || !scale || !shift || !w || !out || !dout || !da || !dw || !db) MRISR_FAIL(MRISR_E_ARG, "head_backward: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec || C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "head_backward: C %d", C);
     const int ppblk = 256 * 8;
     dim3 grid(ceil_div(H * W, ppblk), N);
     const size_t lds = (C + 1) * sizeof(float);
     if (dtype == MRISR_BF16) head_bwd_kernel<bf16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, w, out, dout, (bf16_t*)da, dw, db, H * W, C, ppblk);
+    else if (dtype == MRISR_F16) head_bwd_kernel<f16_t><<<grid, 256, lds, (hipStream_t)stream>>>((const f16_t*)x, scale, shift, w, out, dout, (f16_t*)da, dw, db, H * W, C, ppblk);
     else if (dtype == MRISR_F32) head_bwd_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>((const float*)x, scale, shift, w, out, dout, (float*)da, dw, db, H * W, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "head_backward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("head_backward");

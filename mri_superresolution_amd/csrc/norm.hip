@@ -357,7 +357,7 @@ __global__ void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __
 
 static int fill_act_bwd_params(ActBwdParams& p, int dtype, int nconsumers, const mrisr_consumer* consumers,
                                const float* blend_alpha, int H, int W, int C, const char* who) {
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     for (int k = 0; k < nconsumers; ++k) {
         const mrisr_consumer& c = consumers[k];
         if (!c.da) MRISR_FAIL(MRISR_E_ARG, "%s: consumer %d null", who, k);
@@ -375,7 +375,7 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
                                          const float* coef, void* dx, int N, int H, int W, int C, void* stream) {
     if (!x || !scale || !shift || !coef || !dx || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: null pointer");
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: %d consumers", nconsumers);
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
     bool plain = true;
     for (int k = 0; k < nconsumers; ++k) plain = plain && consumers[k].spatial == MRISR_SP_NONE;
@@ -397,6 +397,7 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
         p.pix_per_block = ppw;
         dim3 gridw(ceil_div(HWp, ppw), N, nslice);
         if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, true><<<gridw, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+        else if (dtype == MRISR_F16) act_bwd_pool_window_kernel<f16_t, true><<<gridw, 256, 0, s>>>(p, coef, (f16_t*)dx);
         else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, true><<<gridw, 256, 0, s>>>(p, coef, (float*)dx);
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
         MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
@@ -413,6 +414,9 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     if (dtype == MRISR_BF16) {
         if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
         else act_bwd_apply_fused_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+    } else if (dtype == MRISR_F16) {
+        if (same) act_bwd_apply_fused_kernel<f16_t, true><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx);
+        else act_bwd_apply_fused_kernel<f16_t, false><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx);
     } else if (dtype == MRISR_F32) {
         if (same) act_bwd_apply_fused_kernel<float, true><<<grid, 256, 0, s>>>(p, coef, (float*)dx);
         else act_bwd_apply_fused_kernel<float, false><<<grid, 256, 0, s>>>(p, coef, (float*)dx);
@@ -427,7 +431,7 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
                                     int W, int C, int groups, void* stream) {
     if (!x || !scale || !shift || !meanrstd || !red || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: null pointer");
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: %d consumers", nconsumers);
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec || groups <= 0 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: C %d", C);
     ActBwdParams p;
     memset(&p, 0, sizeof(p));
@@ -459,6 +463,7 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
         dim3 gridw(ceil_div(HWp, ppw), N, nslice);
         hipStream_t sw = (hipStream_t)stream;
         if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (bf16_t*)nullptr);
+        else if (dtype == MRISR_F16) act_bwd_pool_window_kernel<f16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (f16_t*)nullptr);
         else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, false><<<gridw, 256, 0, sw>>>(p, nullptr, (float*)nullptr);
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
         MRISR_CHECK_LAUNCH("act_bwd_reduce");
@@ -478,6 +483,10 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
         if (kind == 0) act_bwd_reduce_kernel<bf16_t, 0><<<grid, 256, 0, s>>>(p);
         else if (kind == 1) act_bwd_reduce_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p);
         else act_bwd_reduce_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p);
+    } else if (dtype == MRISR_F16) {
+        if (kind == 0) act_bwd_reduce_kernel<f16_t, 0><<<grid, 256, 0, s>>>(p);
+        else if (kind == 1) act_bwd_reduce_kernel<f16_t, 1><<<grid, 256, 0, s>>>(p);
+        else act_bwd_reduce_kernel<f16_t, 2><<<grid, 256, 0, s>>>(p);
     } else if (dtype == MRISR_F32) {
         if (kind == 0) act_bwd_reduce_kernel<float, 0><<<grid, 256, 0, s>>>(p);
         else if (kind == 1) act_bwd_reduce_kernel<float, 1><<<grid, 256, 0, s>>>(p);
@@ -715,7 +724,7 @@ __global__ __launch_bounds__(256) void act_bwd_apply_unshuffle_kernel(const T* _
 extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N, int H,
                                    int W, int C, int out_mode, float* dbias, void* stream) {
     if (!x || !g || !coef || !dx) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: C %d", C);
     if (out_mode == MRISR_OUT_PIXEL_SHUFFLE2 && ((H | W) & 1)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply: odd dims with pixel shuffle");
     const size_t total = (size_t)N * H * W * (C / vec);
@@ -728,6 +737,8 @@ extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, cons
         const int blocks = dbias ? (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024) : (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         if (dtype == MRISR_BF16)
             act_bwd_apply_unshuffle_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C, dbias);
+        else if (dtype == MRISR_F16)
+            act_bwd_apply_unshuffle_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, (const f16_t*)g, coef, (f16_t*)dx, N, H, W, C, dbias);
         else if (dtype == MRISR_F32)
             act_bwd_apply_unshuffle_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)g, coef, (float*)dx, N, H, W, C, dbias);
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply: dtype %d", dtype);
@@ -736,6 +747,8 @@ extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, cons
     }
     if (dtype == MRISR_BF16)
         act_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)g, coef, (bf16_t*)dx, N, H, W, C, out_mode);
+    else if (dtype == MRISR_F16)
+        act_bwd_apply_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, (const f16_t*)g, coef, (f16_t*)dx, N, H, W, C, out_mode);
     else if (dtype == MRISR_F32)
         act_bwd_apply_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)g, coef, (float*)dx, N, H, W, C, out_mode);
     else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply: dtype %d", dtype);
@@ -775,12 +788,13 @@ extern "C" int mrisr_norm_blend(int dtype, const void* x0, const float* scale0, 
                                 const float* scale1, const float* shift1, const float* alpha, void* out, int N, int H,
                                 int W, int C, void* stream) {
     if (!x0 || !scale0 || !shift0 || !x1 || !scale1 || !shift1 || !alpha || !out) MRISR_FAIL(MRISR_E_ARG, "norm_blend: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (N <= 0 || H <= 0 || W <= 0 || C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_blend: N %d H %d W %d C %d", N, H, W, C);
     const size_t total = (size_t)N * H * W * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MRISR_BF16) norm_blend_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x0, scale0, shift0, (const bf16_t*)x1, scale1, shift1, alpha, (bf16_t*)out, N, (size_t)H * W, C);
+    else if (dtype == MRISR_F16) norm_blend_kernel<f16_t><<<blocks, 256, 0, s>>>((const f16_t*)x0, scale0, shift0, (const f16_t*)x1, scale1, shift1, alpha, (f16_t*)out, N, (size_t)H * W, C);
     else if (dtype == MRISR_F32) norm_blend_kernel<float><<<blocks, 256, 0, s>>>((const float*)x0, scale0, shift0, (const float*)x1, scale1, shift1, alpha, (float*)out, N, (size_t)H * W, C);
     else MRISR_FAIL(MRISR_E_DTYPE, "norm_blend: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("norm_blend");
@@ -824,12 +838,14 @@ extern "C" int mrisr_blend_alpha_grad(int dtype, const void* da, const void* x0,
                                       const float* shift0, const void* x1, const float* scale1, const float* shift1,
                                       const float* alpha, float* dalpha, int N, int H, int W, int C, void* stream) {
     if (!da || !x0 || !x1 || !scale0 || !shift0 || !scale1 || !shift1 || !alpha || !dalpha) MRISR_FAIL(MRISR_E_ARG, "blend_alpha_grad: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "blend_alpha_grad: C %d", C);
     const size_t total = (size_t)N * H * W * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (dtype == MRISR_BF16)
         blend_alpha_grad_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)da, (const bf16_t*)x0, scale0, shift0, (const bf16_t*)x1, scale1, shift1, alpha, dalpha, N, H * W, C);
+    else if (dtype == MRISR_F16)
+        blend_alpha_grad_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)da, (const f16_t*)x0, scale0, shift0, (const f16_t*)x1, scale1, shift1, alpha, dalpha, N, H * W, C);
     else if (dtype == MRISR_F32)
         blend_alpha_grad_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)da, (const float*)x0, scale0, shift0, (const float*)x1, scale1, shift1, alpha, dalpha, N, H * W, C);
     else MRISR_FAIL(MRISR_E_DTYPE, "blend_alpha_grad: dtype %d", dtype);
@@ -871,12 +887,13 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
 
 extern "C" int mrisr_channel_sum(int dtype, const void* x, float* out, size_t npix, int C, void* stream) {
     if (!x || !out) MRISR_FAIL(MRISR_E_ARG, "channel_sum: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec || C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "channel_sum: C %d", C);
     const int ppb = 256 / (C / vec);
     const int ppblk = ppb * 32;
     const int blocks = (int)((npix + ppblk - 1) / ppblk);
     if (dtype == MRISR_BF16) channel_sum_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, out, npix, C, ppblk);
+    else if (dtype == MRISR_F16) channel_sum_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, out, npix, C, ppblk);
     else if (dtype == MRISR_F32) channel_sum_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, out, npix, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "channel_sum: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("channel_sum");
@@ -918,6 +935,7 @@ int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int 
     const int ppblk = 1024;
     dim3 grid(ceil_div(HW, ppblk), N);
     if (dtype == MRISR_BF16) gn_stats_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, stats, HW, C, groups, ppblk);
+    else if (dtype == MRISR_F16) gn_stats_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, stats, HW, C, groups, ppblk);
     else gn_stats_kernel<float><<<grid, 256, 0, s>>>((const float*)x, stats, HW, C, groups, ppblk);
     MRISR_CHECK_LAUNCH("gn_stats");
     return MRISR_OK;
@@ -960,11 +978,12 @@ __global__ __launch_bounds__(256) void norm_pool2_kernel(const T* __restrict__ x
 extern "C" int mrisr_norm_pool2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
                                 int H, int W, int C, void* stream) {
     if (!x || !scale || !shift || !out) MRISR_FAIL(MRISR_E_ARG, "norm_pool2: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec || H < 2 || W < 2) MRISR_FAIL(MRISR_E_SHAPE, "norm_pool2: C %d H %d W %d", C, H, W);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == MRISR_BF16) norm_pool2_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, H, W, C);
+    else if (dtype == MRISR_F16) norm_pool2_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, scale, shift, (f16_t*)out, N, H, W, C);
     else if (dtype == MRISR_F32) norm_pool2_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, H, W, C);
     else MRISR_FAIL(MRISR_E_DTYPE, "norm_pool2: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("norm_pool2");
@@ -1030,12 +1049,13 @@ __global__ __launch_bounds__(256) void upsample2_stats_kernel(const T* __restric
 extern "C" int mrisr_upsample2_stats(int dtype, const void* z_low, void* z, double* stats, int N, int h, int w, int C,
                                      int groups, void* stream) {
     if (!z_low || !z) MRISR_FAIL(MRISR_E_ARG, "upsample2_stats: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec || C / vec > 256 || groups <= 0 || groups > 64 || C % groups) MRISR_FAIL(MRISR_E_SHAPE, "upsample2_stats: C %d groups %d", C, groups);
     const int ppb = 256 / (C / vec);
     const int ppblk = ppb * 16;
     dim3 grid(ceil_div(4 * h * w, ppblk), N);
     if (dtype == MRISR_BF16) upsample2_stats_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)z_low, (bf16_t*)z, stats, h, w, C, groups, ppblk);
+    else if (dtype == MRISR_F16) upsample2_stats_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const f16_t*)z_low, (f16_t*)z, stats, h, w, C, groups, ppblk);
     else if (dtype == MRISR_F32) upsample2_stats_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)z_low, (float*)z, stats, h, w, C, groups, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "upsample2_stats: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("upsample2_stats");
@@ -1090,11 +1110,12 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restr
 
 extern "C" int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, int N, int h, int w, int C, void* stream) {
     if (!dz || !dz_low) MRISR_FAIL(MRISR_E_ARG, "upsample2_adjoint: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "upsample2_adjoint: C %d", C);
     const size_t total = (size_t)N * h * w * (C / vec);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == MRISR_BF16) upsample2_adjoint_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)dz, (bf16_t*)dz_low, N, h, w, C);
+    else if (dtype == MRISR_F16) upsample2_adjoint_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)dz, (f16_t*)dz_low, N, h, w, C);
     else if (dtype == MRISR_F32) upsample2_adjoint_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)dz_low, N, h, w, C);
     else MRISR_FAIL(MRISR_E_DTYPE, "upsample2_adjoint: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("upsample2_adjoint");
@@ -1143,7 +1164,7 @@ __global__ __launch_bounds__(256) void norm_upsample2_kernel(const T* __restrict
 extern "C" int mrisr_norm_upsample2(int dtype, const void* x, const float* scale, const float* shift, void* out, int N,
                                     int h, int w, int C, void* stream) {
     if (!x || !scale || !shift || !out) MRISR_FAIL(MRISR_E_ARG, "norm_upsample2: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d", C);
     if (C / vec > 256 || N <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d N %d", C, N);
     const int nvec = C / vec, ppb = 256 / nvec, HW = 4 * h * w;
@@ -1151,6 +1172,7 @@ extern "C" int mrisr_norm_upsample2(int dtype, const void* x, const float* scale
     if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
     dim3 grid(ceil_div(HW, ppblk), N);
     if (dtype == MRISR_BF16) norm_upsample2_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, h, w, C, ppblk);
+    else if (dtype == MRISR_F16) norm_upsample2_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, scale, shift, (f16_t*)out, N, h, w, C, ppblk);
     else if (dtype == MRISR_F32) norm_upsample2_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, h, w, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "norm_upsample2: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("norm_upsample2");

@@ -166,6 +166,7 @@ extern "C" int mrisr_vgg_input_forward(int dtype, const float* x, void* out, siz
     if (!x || !out) MRISR_FAIL(MRISR_E_ARG, "vgg_input_forward: null pointer");
     if (!npix) return MRISR_OK;
     if (dtype == MRISR_BF16) vgg_input_fwd_kernel<bf16_t><<<grid_for(npix), 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)out, npix, vgg_norm());
+    else if (dtype == MRISR_F16) vgg_input_fwd_kernel<f16_t><<<grid_for(npix), 256, 0, (hipStream_t)stream>>>(x, (f16_t*)out, npix, vgg_norm());
     else if (dtype == MRISR_F32) vgg_input_fwd_kernel<float><<<grid_for(npix), 256, 0, (hipStream_t)stream>>>(x, (float*)out, npix, vgg_norm());
     else MRISR_FAIL(MRISR_E_DTYPE, "vgg_input_forward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("vgg_input_forward");
@@ -177,6 +178,7 @@ extern "C" int mrisr_vgg_input_backward(int dtype, const void* dx3, const float*
     if (!dx3 || !dimg) MRISR_FAIL(MRISR_E_ARG, "vgg_input_backward: null pointer");
     if (!npix) return MRISR_OK;
     if (dtype == MRISR_BF16) vgg_input_bwd_kernel<bf16_t><<<grid_for(npix), 256, 0, (hipStream_t)stream>>>((const bf16_t*)dx3, gscale, scale, dimg, npix, vgg_norm());
+    else if (dtype == MRISR_F16) vgg_input_bwd_kernel<f16_t><<<grid_for(npix), 256, 0, (hipStream_t)stream>>>((const f16_t*)dx3, gscale, scale, dimg, npix, vgg_norm());
     else if (dtype == MRISR_F32) vgg_input_bwd_kernel<float><<<grid_for(npix), 256, 0, (hipStream_t)stream>>>((const float*)dx3, gscale, scale, dimg, npix, vgg_norm());
     else MRISR_FAIL(MRISR_E_DTYPE, "vgg_input_backward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("vgg_input_backward");
@@ -185,10 +187,11 @@ extern "C" int mrisr_vgg_input_backward(int dtype, const void* dx3, const float*
 
 extern "C" int mrisr_maxpool2_forward(int dtype, const void* x, void* out, int N, int H, int W, int C, void* stream) {
     if (!x || !out) MRISR_FAIL(MRISR_E_ARG, "maxpool2_forward: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (N <= 0 || C <= 0 || C % vec || H < 2 || W < 2) MRISR_FAIL(MRISR_E_SHAPE, "maxpool2_forward: N %d C %d H %d W %d", N, C, H, W);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / vec);
     if (dtype == MRISR_BF16) maxpool2_fwd_kernel<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)out, N, H, W, C);
+    else if (dtype == MRISR_F16) maxpool2_fwd_kernel<f16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const f16_t*)x, (f16_t*)out, N, H, W, C);
     else if (dtype == MRISR_F32) maxpool2_fwd_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)out, N, H, W, C);
     else MRISR_FAIL(MRISR_E_DTYPE, "maxpool2_forward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("maxpool2_forward");
@@ -198,10 +201,11 @@ extern "C" int mrisr_maxpool2_forward(int dtype, const void* x, void* out, int N
 extern "C" int mrisr_maxpool2_backward(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
                                        int relu_gate, void* stream) {
     if (!x || !dy || !dx) MRISR_FAIL(MRISR_E_ARG, "maxpool2_backward: null pointer");
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (N <= 0 || C <= 0 || C % vec || H < 2 || W < 2) MRISR_FAIL(MRISR_E_SHAPE, "maxpool2_backward: N %d C %d H %d W %d", N, C, H, W);
     const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
     if (dtype == MRISR_BF16) maxpool2_bwd_kernel<bf16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, relu_gate);
+    else if (dtype == MRISR_F16) maxpool2_bwd_kernel<f16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const f16_t*)x, (const f16_t*)dy, (f16_t*)dx, N, H, W, C, relu_gate);
     else if (dtype == MRISR_F32) maxpool2_bwd_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const float*)x, (const float*)dy, (float*)dx, N, H, W, C, relu_gate);
     else MRISR_FAIL(MRISR_E_DTYPE, "maxpool2_backward: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("maxpool2_backward");
@@ -212,13 +216,14 @@ extern "C" int mrisr_feature_loss(int dtype, const void* a, const void* b, size_
                                   float* out, void* da, int relu_gate, void* stream) {
     if (!a || !b || !sum16 || !out) MRISR_FAIL(MRISR_E_ARG, "feature_loss: null pointer");
     if (kind != 0 && kind != 1) MRISR_FAIL(MRISR_E_ARG, "feature_loss: kind %d", kind);
-    const int vec = dtype == MRISR_BF16 ? 8 : 4;
+    const int vec = mrisr_vec(dtype);
     if (!n || n % vec) MRISR_FAIL(MRISR_E_SHAPE, "feature_loss: %zu elements not a multiple of %d", n, vec);
     const size_t nvecs = n / vec;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(sum16, 0, 16 * sizeof(double), s) != hipSuccess) MRISR_FAIL(MRISR_E_HIP, "feature_loss: memset");
     const int blocks = (int)((nvecs + 255) / 256 < 2048 ? (nvecs + 255) / 256 : 2048);
     if (dtype == MRISR_BF16) feature_loss_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)b, nvecs, kind, sum16, (bf16_t*)da, relu_gate);
+    else if (dtype == MRISR_F16) feature_loss_kernel<f16_t><<<blocks, 256, 0, s>>>((const f16_t*)a, (const f16_t*)b, nvecs, kind, sum16, (f16_t*)da, relu_gate);
     else if (dtype == MRISR_F32) feature_loss_kernel<float><<<blocks, 256, 0, s>>>((const float*)a, (const float*)b, nvecs, kind, sum16, (float*)da, relu_gate);
     else MRISR_FAIL(MRISR_E_DTYPE, "feature_loss: dtype %d", dtype);
     feature_loss_finalize_kernel<<<1, 1, 0, s>>>(sum16, (double)n, out);

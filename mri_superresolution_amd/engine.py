@@ -27,9 +27,11 @@ GN_EPS = 1e-5
 def _dt(dtype: torch.dtype) -> int:
     if dtype == torch.bfloat16:
         return L.BF16
+    if dtype == torch.float16:
+        return L.F16
     if dtype == torch.float32:
         return L.F32
-    raise ValueError(f"unsupported compute dtype {dtype} (use torch.float32 or torch.bfloat16)")
+    raise ValueError(f"unsupported compute dtype {dtype} (use torch.float32, torch.float16 or torch.bfloat16)")
 
 
 # order of the two convolutions of a layer's backward step (tuning: MRISR_WGRAD_LAST=1 runs dgrad first)

@@ -247,13 +247,18 @@ class UNetSuperRes(nn.Module):
     def _resolve_dtype(self):
         if self.compute_dtype is not None:
             return self.compute_dtype
-        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        # under torch.amp.autocast the compute dtype is autocast's: fp16 by default, as in the reference's
+        # `with autocast(device_type='cuda')` (scripts/train.py:303-306), bf16 when the caller asked for it
+        if torch.is_autocast_enabled("cuda"):
+            return torch.get_autocast_dtype("cuda")
+        return torch.float32
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 (exact-fp32 MFMA, parity path), torch.bfloat16 (bf16 MFMA, fp32 accumulate)
+        """torch.float32 (exact-fp32 MFMA, parity path), torch.bfloat16 / torch.float16 (16-bit storage and MFMA
+        operands, fp32 accumulate / statistics / masters; fp16 needs loss scaling: torch.amp.GradScaler + FusedAdam)
         or None (follow torch.autocast)."""
-        if dtype not in (None, torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be None, torch.float32 or torch.bfloat16")
+        if dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("compute dtype must be None, torch.float32, torch.float16 or torch.bfloat16")
         self.compute_dtype = dtype
         return self
 

@@ -6,6 +6,10 @@ Drop-in for ``optim.Adam(model.parameters(), lr, weight_decay)`` as used by
 (train.py:189-191) because it is a ``torch.optim.Optimizer`` with one param group.
 ``state_dict()`` is emitted in torch.optim.Adam's layout (per-parameter ``step`` / ``exp_avg`` /
 ``exp_avg_sq``) so checkpoints stay interchangeable (train.py:410-418).
+
+fp16 autocast (train.py:303-311): ``scaler.step(optimizer)`` of ``torch.amp.GradScaler`` works unchanged - the class
+advertises ``_step_supports_amp_scaling``, so the scaler hands over its ``grad_scale`` / ``found_inf`` DEVICE tensors
+and the kernel un-scales, skips on overflow and counts steps on the device: no host synchronisation per step.
 """
 from __future__ import annotations
 
@@ -15,13 +19,16 @@ from . import _lib as L
 
 
 class FusedAdam(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True      # torch.amp.GradScaler.step: pass grad_scale / found_inf tensors, do not unscale
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         if not hasattr(model, "flat_params"):
             raise TypeError("FusedAdam needs a model with flat parameter storage (UNetSuperRes)")
         self.model = model
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step = 0
-        self.grad_scale = 1.0           # 1/world_size when gradients were sum-all-reduced
+        self._step_dev = None           # int32 device counter, used from the first GradScaler-driven step on
+        self.dp_grad_scale = 1.0        # 1/world_size when gradients were sum-all-reduced (data parallel)
         self._alloc()
 
     def _alloc(self):
@@ -47,11 +54,23 @@ class FusedAdam(torch.optim.Optimizer):
             if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
                 gv.copy_(p.grad)                            # foreign gradient tensor: stage it
         g = self.param_groups[0]
-        self._step += 1
-        L.call("mrisr_adam_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
-               self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
-               float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, float(self.grad_scale),
-               L.stream_ptr())
+        # torch.amp.GradScaler.step sets these two attributes (device tensors) around its call of step()
+        loss_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        if loss_scale is not None or found_inf is not None or self._step_dev is not None:
+            if self._step_dev is None:      # first scaled step: the count moves to the device (skipped steps do not count)
+                self._step_dev = torch.tensor([self._step], dtype=torch.int32, device=m.flat_params.device)
+            ls = None if loss_scale is None else loss_scale.detach().to(torch.float32).reshape(-1)
+            fi = None if found_inf is None else found_inf.detach().to(torch.float32).reshape(-1)
+            L.call("mrisr_adam_step_amp", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
+                   self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
+                   float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step_dev.data_ptr(),
+                   float(self.dp_grad_scale), L.ptr(ls), L.ptr(fi), L.stream_ptr())
+        else:
+            self._step += 1
+            L.call("mrisr_adam_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
+                   self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
+                   float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, float(self.dp_grad_scale),
+                   L.stream_ptr())
         m.mark_weights_changed()        # the kernel wrote the masters through raw pointers: packed images are stale
         return loss
 
@@ -69,14 +88,20 @@ class FusedAdam(torch.optim.Optimizer):
             out.append(v)
         return out
 
+    @property
+    def step_count(self) -> int:
+        """Optimiser steps taken (reads the device counter back when a GradScaler drives the steps)."""
+        return int(self._step_dev.item()) if self._step_dev is not None else self._step
+
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
         n = len(self.param_groups[0]["params"])
         groups[0]["params"] = list(range(n))
         state = {}
-        if self._step > 0:
+        step = self.step_count
+        if step > 0:
             for i, (ea, es) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq))):
-                state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": ea.clone(), "exp_avg_sq": es.clone()}
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": ea.clone(), "exp_avg_sq": es.clone()}
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
@@ -93,3 +118,5 @@ class FusedAdam(torch.optim.Optimizer):
                 ea.copy_(ent["exp_avg"])
                 es.copy_(ent["exp_avg_sq"])
                 self._step = int(float(ent["step"]))
+                if self._step_dev is not None:
+                    self._step_dev.fill_(self._step)

@@ -8,7 +8,7 @@ The gradient lives in ONE flat fp32 buffer laid out in forward (registration) or
 completes it from the end towards the start, so buckets are contiguous suffix slices that are
 all-reduced (sum) on RCCL's stream as soon as the kernels writing them have been queued -
 overlapping the remaining backward convolutions.  The 1/world_size factor is folded into the fused
-Adam kernel (``FusedAdam.grad_scale``).
+Adam kernel (``FusedAdam.dp_grad_scale``).
 """
 from __future__ import annotations
 
@@ -86,7 +86,7 @@ class GradBucketer:
 
 class DataParallel:
     """Wraps a UNetSuperRes replica: broadcast of the initial weights, bucketed overlapped gradient
-    all-reduce, and scalar metric averaging.  ``optimizer.grad_scale`` must be 1/world_size."""
+    all-reduce, and scalar metric averaging.  ``optimizer.dp_grad_scale`` must be 1/world_size."""
 
     def __init__(self, model, group=None, bucket_bytes: int = 8 << 20):
         if not dist.is_initialized():

@@ -86,6 +86,8 @@ def load_local_vgg19_weights(features: nn.Sequential, path: str) -> None:
 def _dt(dtype: torch.dtype) -> int:
     if dtype == torch.bfloat16:
         return L.BF16
+    if dtype == torch.float16:
+        return L.F16
     if dtype == torch.float32:
         return L.F32
     raise ValueError(f"unsupported compute dtype {dtype}")

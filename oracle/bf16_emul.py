@@ -21,31 +21,32 @@ from .losses_ref import combined_loss
 ALL = frozenset({"act", "w", "raw", "dy", "dain"})
 
 
-def _r16(x):
-    return x.to(torch.bfloat16).to(x.dtype)
+def _r16(x, dt):
+    return x.to(dt).to(x.dtype)
 
 
 class _Round(torch.autograd.Function):
-    """y = bf16(x) forward (if fwd); dx = bf16(dy) backward (if bwd)."""
+    """y = round16(x) forward (if fwd); dx = round16(dy) backward (if bwd)."""
 
     @staticmethod
-    def forward(ctx, x, fwd, bwd):
-        ctx.bwd = bwd
-        return _r16(x) if fwd else x.clone()
+    def forward(ctx, x, fwd, bwd, dt):
+        ctx.bwd, ctx.dt = bwd, dt
+        return _r16(x, dt) if fwd else x.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return (_r16(g) if ctx.bwd else g), None, None
+        return (_r16(g, ctx.dt) if ctx.bwd else g), None, None, None
 
 
-def emulated_grads(sd, low, high, ssim_weight=0.4, knobs=ALL, depth=4):
-    """(grads dict, output) of the oracle with the given bf16 storage points emulated."""
+def emulated_grads(sd, low, high, ssim_weight=0.4, knobs=ALL, depth=4, dtype=torch.bfloat16, grad_scale=1.0):
+    """(grads dict, output) of the oracle with the given 16-bit storage points emulated (``dtype`` = torch.bfloat16 or
+    torch.float16; ``grad_scale``: loss scale of the fp16 path - the stored backward tensors are rounded at that scale)."""
     real = F.conv2d
 
     def conv(x, w, b=None, **kw):
-        x = _Round.apply(x, "act" in knobs, "dain" in knobs)
-        w = _Round.apply(w, "w" in knobs, False)
-        return _Round.apply(real(x, w, b, **kw), "raw" in knobs, "dy" in knobs)
+        x = _Round.apply(x, "act" in knobs, "dain" in knobs, dtype)
+        w = _Round.apply(w, "w" in knobs, False, dtype)
+        return _Round.apply(real(x, w, b, **kw), "raw" in knobs, "dy" in knobs, dtype)
 
     params = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in sd.items())
     unet_ref.F.conv2d = conv            # the functional restatement looks F.conv2d up at call time
@@ -54,8 +55,8 @@ def emulated_grads(sd, low, high, ssim_weight=0.4, knobs=ALL, depth=4):
     finally:
         unet_ref.F.conv2d = real
     loss = combined_loss(out, high, ssim_weight)
-    g = torch.autograd.grad(loss, list(params.values()))
-    return OrderedDict(zip(params.keys(), g)), out.detach()
+    g = torch.autograd.grad(loss * grad_scale, list(params.values()))
+    return OrderedDict(zip(params.keys(), [t / grad_scale for t in g])), out.detach()
 
 
 def cos_ratio(g, ref):

@@ -118,7 +118,7 @@ def _load01(path: str) -> np.ndarray:
 def run_benchmarks(test_pairs, model, device, use_amp: bool = False):
     """Rows of {image, method, ssim, mse, rmse, mae, psnr, time} (evaluate.py:62-108)."""
     from scripts.infer import preprocess_image
-    model.set_compute_dtype(torch.bfloat16 if use_amp else torch.float32)
+    model.set_compute_dtype(torch.float16 if use_amp else torch.float32)   # reference: torch.amp.autocast("cuda") = fp16
     rows = []
     for lr_path, hr_path in test_pairs:
         hr_img = _load01(hr_path)

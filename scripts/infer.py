@@ -108,7 +108,7 @@ def process_single_image(model, input_path, output_path, target_path=None, devic
     if target_path:
         target_img, target = preprocess_image(target_path)
         target = target.to(device)
-    model.set_compute_dtype(torch.bfloat16 if use_amp else torch.float32)
+    model.set_compute_dtype(torch.float16 if use_amp else torch.float32)   # reference: torch.amp.autocast("cuda") = fp16
     with torch.no_grad():
         out = model(x).clamp(0.0, 1.0)
     metrics = None
@@ -160,7 +160,7 @@ def parse_args(argv=None):
     p.add_argument("--show_comparison", action="store_true")
     p.add_argument("--show_diff", action="store_true")
     p.add_argument("--cpu", action="store_true", help="accepted for CLI compatibility; not supported (GPU-only build)")
-    p.add_argument("--use_amp", action="store_true", help="bf16 MFMA compute")
+    p.add_argument("--use_amp", action="store_true", help="fp16 MFMA compute (the reference's autocast)")
     return p.parse_args(argv)
 
 

@@ -3,8 +3,10 @@
 stdout protocol, checkpoint file names and dict keys, loop order :296-323).
 
 Differences by design: the model / loss / optimizer run in hand-written HIP kernels (no CPU path: ``--cpu``
-is accepted for CLI compatibility and fails loudly); ``--use_amp`` selects bf16 MFMA compute (no GradScaler
-needed); launched under ``torch.distributed.run`` it trains data-parallel over RCCL (one process per GPU,
+is accepted for CLI compatibility and fails loudly); ``--use_amp`` is the reference's AMP (train.py:158-163,
+303-311): ``torch.amp.autocast`` in fp16 + ``torch.amp.GradScaler`` (f16 MFMA kernels; the scaler's unscale / overflow
+skip run inside the fused Adam kernel, no host sync per step), ``--amp_dtype bf16`` (extension) selects bf16 MFMA
+compute without loss scaling; launched under ``torch.distributed.run`` it trains data-parallel over RCCL (one process per GPU,
 rank-0 logging / checkpoints, validation loss averaged over ranks so every rank takes the same scheduler /
 early-stopping decisions).
 """
@@ -121,21 +123,26 @@ def train(args):
     torch.manual_seed(args.seed)
     random.seed(args.seed)
     log_message(f"Using device: {device} ({torch.cuda.get_device_name(local_rank)}), world size {world}")
+    amp_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.amp_dtype]
+    scaler = None
     if args.use_amp:
-        log_message("Using bf16 MFMA compute (fp32 accumulate, statistics and master weights).")
+        # reference train.py:158-163: autocast + GradScaler ("Using Automatic Mixed Precision (AMP) training.")
+        scaler = torch.amp.GradScaler("cuda") if amp_dtype == torch.float16 else None
+        log_message(f"Using Automatic Mixed Precision (AMP) training: {args.amp_dtype} MFMA compute, fp32 accumulate / "
+                    f"statistics / master weights" + (", dynamic loss scaling (GradScaler)." if scaler else "."))
 
     if args.model_type != "unet":
         raise ValueError(f"Unknown model type: {args.model_type}")
     model = UNetSuperRes(in_channels=1, out_channels=1, base_filters=args.base_filters,
                          initial_alpha=args.initial_alpha).to(device)
-    model.set_compute_dtype(torch.bfloat16 if args.use_amp else torch.float32)
+    model.set_compute_dtype(None if args.use_amp else torch.float32)      # None: follow torch.amp.autocast
     optimizer = FusedAdam(model, lr=args.learning_rate, weight_decay=args.weight_decay)
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5,
                                                            patience=args.patience // 2)
     dp = None
     if world > 1:
         dp = DataParallel(model)
-        optimizer.grad_scale = 1.0 / world
+        optimizer.dp_grad_scale = 1.0 / world
 
     dataset = MRISuperResDataset(args.full_res_dir, args.low_res_dir, augmentation=args.augmentation)
     n_val = int(len(dataset) * args.validation_split)
@@ -178,12 +185,25 @@ def train(args):
         for batch_idx, (low, high) in enumerate(loader):
             low, high = low.to(device, non_blocking=True), high.to(device, non_blocking=True)
             optimizer.zero_grad(set_to_none=True)
-            output = model(low)
-            loss = criterion(output, high)
-            loss.backward()
-            if dp is not None:
-                dp.finish_gradients()
-            optimizer.step()
+            if args.use_amp:                     # reference train.py:303-311
+                with torch.amp.autocast("cuda", dtype=amp_dtype):
+                    output = model(low)
+                    loss = criterion(output, high)
+                (scaler.scale(loss) if scaler else loss).backward()
+                if dp is not None:
+                    dp.finish_gradients()        # scaled gradients are summed; the overflow check sees the reduced values
+                if scaler:
+                    scaler.step(optimizer)
+                    scaler.update()
+                else:
+                    optimizer.step()
+            else:                                # reference train.py:313-318
+                output = model(low)
+                loss = criterion(output, high)
+                loss.backward()
+                if dp is not None:
+                    dp.finish_gradients()
+                optimizer.step()
             with torch.no_grad():
                 acc[0] += loss.detach()
                 acc[1] += ssim_metric(output, high)
@@ -202,7 +222,8 @@ def train(args):
             with torch.no_grad():
                 for low, high in val_loader:
                     low, high = low.to(device, non_blocking=True), high.to(device, non_blocking=True)
-                    out = model(low)
+                    with torch.amp.autocast("cuda", dtype=amp_dtype, enabled=args.use_amp):
+                        out = model(low)
                     vacc[0] += criterion(out, high)
                     vacc[1] += ssim_metric(out, high)
                     vacc[2] += 1
@@ -275,7 +296,9 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=random.randint(1, 10000))
     p.add_argument("--augmentation", action="store_true")
     p.add_argument("--use_tensorboard", action="store_true")
-    p.add_argument("--use_amp", action="store_true", help="bf16 MFMA compute")
+    p.add_argument("--use_amp", action="store_true", help="Use Automatic Mixed Precision training (fp16 autocast + GradScaler)")
+    p.add_argument("--amp_dtype", type=str, default="fp16", choices=["fp16", "bf16"],
+                   help="(extension) autocast dtype of --use_amp: fp16 as the reference, or bf16 without loss scaling")
     p.add_argument("--cpu", action="store_true", help="accepted for CLI compatibility; not supported (GPU-only build)")
     p.add_argument("--checkpoint_dir", type=str, default="./checkpoints")
     p.add_argument("--log_dir", type=str, default="./logs")

@@ -13,7 +13,7 @@ DEV = "cuda"
 
 
 def tdt(dt):
-    return torch.bfloat16 if dt == L.BF16 else torch.float32
+    return {L.BF16: torch.bfloat16, L.F16: torch.float16}.get(dt, torch.float32)
 
 
 def nhwc(x_nchw: torch.Tensor, dt) -> torch.Tensor:

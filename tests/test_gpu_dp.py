@@ -45,7 +45,7 @@ def run(m, opt, lo, hi, dp=None, steps=2):
             dp.finish_gradients()
         if i == 0:
             torch.cuda.current_stream().synchronize()
-            g1 = m.flat_grads.clone() * (opt.grad_scale if dp is not None else 1.0)
+            g1 = m.flat_grads.clone() * (opt.dp_grad_scale if dp is not None else 1.0)
         opt.step()
         losses.append(loss.detach())
     torch.cuda.synchronize()
@@ -55,7 +55,7 @@ m = build(3 + rank)                                  # different weights per ran
 dp = DataParallel(m, bucket_bytes=100_000)
 assert len(dp.bucketer.bounds) > 3
 opt = FusedAdam(m, lr=1e-3, weight_decay=1e-5)
-opt.grad_scale = 1.0 / world
+opt.dp_grad_scale = 1.0 / world
 sl = slice(rank * per_rank, (rank + 1) * per_rank)
 losses, g_dp = run(m, opt, low[sl], high[sl], dp)
 mean_loss = dp.average_scalars(losses)

@@ -100,7 +100,10 @@ def test_c2_width_bf16_psnr_ssim_and_gradients(c2_reference):
         ecos, eratio = cos_ratio(emu[k], r["grads"][k])
         _report(f"C2-width grads bf16 {k}: cosine {cos:.4f} norm ratio {ratio:.3f} (emulated: {ecos:.4f} / {eratio:.3f})")
         assert cos >= min(0.95, ecos - 0.03), f"{k}: cosine {cos:.4f} (emulated {ecos:.4f})"
-        assert abs(ratio - 1.0) <= 0.10 + abs(eratio - 1.0), f"{k}: norm ratio {ratio:.3f} (emulated {eratio:.3f})"
+        # (scalar parameters - alpha, the output bias - are single cancelling sums: the emulation moves them by 0.56x ... 1.5x
+        # across seeds, profiles/r02_bf16_grad_attribution.txt, so only their sign and order of magnitude are gated)
+        band = 0.6 if p.numel() == 1 else 0.10 + abs(eratio - 1.0)
+        assert abs(ratio - 1.0) <= band, f"{k}: norm ratio {ratio:.3f} (emulated {eratio:.3f})"
 
 
 def test_c1_three_train_steps_l1_only():

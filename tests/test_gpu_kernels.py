@@ -3,7 +3,9 @@ with the torch-CPU fp32 restatement of the same reference op.
 
 Tolerances: fp32 path (exact-fp32 MFMA) 2e-5 of the tensor's max (summation order only);
 bf16 path: operands are rounded to bf16 on BOTH sides, so the remaining error is the bf16 rounding
-of the stored result (2^-8 relative) -> 1e-2 of max for stored tensors, 2e-3 for fp32 outputs.
+of the stored result (2^-8 relative) -> 1e-2 of max for stored tensors, 2e-3 for fp32 outputs;
+fp16 path (MRISR_F16, 2^-11 relative): 2e-3 / 5e-4 (NORM-source convs: the loader's packed fp16 GroupNorm + LeakyReLU
+rounds three times where the reference rounds once -> those cases use the bf16 tolerance).
 """
 import ctypes as C
 
@@ -17,9 +19,10 @@ pytestmark = pytest.mark.gpu
 from mri_superresolution_amd import _lib as L          # noqa: E402
 import hiputil as U                                    # noqa: E402
 
-DTS = [L.F32, L.BF16]
-TOL_OUT = {L.F32: 2e-5, L.BF16: 1e-2}      # stored in compute dtype
-TOL_F32 = {L.F32: 2e-5, L.BF16: 2e-3}      # fp32 results computed from rounded operands
+DTS = [L.F32, L.BF16, L.F16]
+TOL_OUT = {L.F32: 2e-5, L.BF16: 1e-2, L.F16: 2e-3}      # stored in compute dtype
+TOL_F32 = {L.F32: 2e-5, L.BF16: 2e-3, L.F16: 5e-4}      # fp32 results computed from rounded operands
+TOL_NORM = {L.F32: 2e-5, L.BF16: 1e-2, L.F16: 1e-2}     # convs whose loader applies GroupNorm + LeakyReLU
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -45,7 +48,7 @@ def test_conv3x3_raw(dt, shape):
     gs = cout // 8
     o = ref.view(n, 8, gs, h, w).double()
     # (groups narrower than 4 channels take the stand-alone statistics pass over the STORED tensor: bf16 rounding)
-    loose = dt == L.BF16 and gs % 4 != 0
+    loose = dt != L.F32 and gs % 4 != 0
     assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=(3e-2 if loose else 1e-3) * o.abs().max().item())
     assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=2e-3 if loose else 1e-4)
 
@@ -64,7 +67,7 @@ def test_conv_streamed_weight_images(dt, shape, ks):
     ref = F.conv2d(U.rounded(x, dt), U.rounded(wt, dt), padding=ks // 2)
     assert U.relerr(out, ref) <= TOL_OUT[dt]
     o = ref.view(n, 8, cout // 8, h, w).double()
-    loose = dt == L.BF16 and (cout // 8) % 4 != 0
+    loose = dt != L.F32 and (cout // 8) % 4 != 0
     assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=(3e-2 if loose else 1e-3) * o.abs().max().item())
 
 
@@ -124,7 +127,7 @@ def test_conv_fused_norm_sources(dt, spatial, ks):
     h, w = {L.SP_NONE: (hs, ws), L.SP_POOL2: (hs // 2, ws // 2), L.SP_UP2: (2 * hs, 2 * ws)}[spatial]
     out, _ = U.conv_forward(dt, [src], wt, h, w, ks)
     ref = F.conv2d(U.ref_conv_input([src], dt, h, w), U.rounded(wt, dt), padding=ks // 2)
-    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    assert U.relerr(out, ref) <= TOL_NORM[dt]
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -136,7 +139,7 @@ def test_conv_concat_with_pad_and_blend(dt):
     srcs = [U.SrcSpec(skip, L.SRC_NORM, L.SP_NONE, *s0), U.SrcSpec(up, L.SRC_NORM, L.SP_NONE, *s1, off=(0, 0))]
     out, _ = U.conv_forward(dt, srcs, wt, h, w, 3)
     ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w), U.rounded(wt, dt), padding=1)
-    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    assert U.relerr(out, ref) <= TOL_NORM[dt]
     # blend of two normalised sources
     a, b = rnd(n, 16, h, w, seed=14), rnd(n, 16, h, w, seed=15)
     alpha = torch.tensor(0.3)
@@ -144,7 +147,7 @@ def test_conv_concat_with_pad_and_blend(dt):
     wt = rnd(16, 16, 3, 3, seed=18, scale=0.1)
     out, _ = U.conv_forward(dt, srcs, wt, h, w, 3, combine=L.COMBINE_BLEND, alpha=alpha)
     ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w, L.COMBINE_BLEND, alpha), U.rounded(wt, dt), padding=1)
-    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    assert U.relerr(out, ref) <= TOL_NORM[dt]
 
 
 @pytest.mark.parametrize("dt", DTS)

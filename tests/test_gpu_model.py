@@ -121,7 +121,10 @@ def test_gradients_bf16_close(golden_dir, seed):
         ecos, eratio = cos_ratio(emu[k], ref_grads[k])
         _report(f"grads bf16 seed {seed} {k}: cosine {cos:.4f} norm ratio {ratio:.3f} (emulated: {ecos:.4f} / {eratio:.3f})")
         assert cos >= min(0.95, ecos - 0.03), f"{k}: cosine {cos:.4f} (emulated {ecos:.4f})"
-        assert abs(ratio - 1.0) <= 0.10 + abs(eratio - 1.0), f"{k}: norm ratio {ratio:.3f} (emulated {eratio:.3f})"
+        # (scalar parameters - alpha, the output bias - are single cancelling sums: the emulation moves them by 0.56x ... 1.5x
+        # across seeds, profiles/r02_bf16_grad_attribution.txt, so only their sign and order of magnitude are gated)
+        band = 0.6 if p.numel() == 1 else 0.10 + abs(eratio - 1.0)
+        assert abs(ratio - 1.0) <= band, f"{k}: norm ratio {ratio:.3f} (emulated {eratio:.3f})"
 
 
 def test_ssim_and_combined_loss_match_reference_golden(golden_dir):

@@ -66,7 +66,7 @@ def test_maxpool2_forward_backward(dt, shape):
     torch.manual_seed(3)
     x = torch.randn(n, c, h, w).relu()            # ReLU output: exact zeros and ties occur
     x[0, :, 0:2, 0:2] = 0.5                       # a full tie: the first element must win
-    tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+    tdt = {L.BF16: torch.bfloat16, L.F16: torch.float16}.get(dt, torch.float32)
     xr = x.to(tdt).float().requires_grad_(True)
     y_ref = F.max_pool2d(xr, 2)
     dy = torch.randn_like(y_ref).to(tdt).float()
@@ -88,7 +88,7 @@ def test_conv_relu_mask_epilogue(dt, tol):
     """dgrad-style conv whose epilogue applies the ReLU backward: out = conv(x) * [mask > 0]."""
     torch.manual_seed(5)
     n, h, w, cin, cout = 2, 20, 37, 32, 64
-    tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+    tdt = {L.BF16: torch.bfloat16, L.F16: torch.float16}.get(dt, torch.float32)
     x = torch.randn(n, cin, h, w).to(tdt).float()
     wt = (torch.randn(cout, cin, 3, 3) * 0.1)
     mask = torch.randn(n, cout, h, w).relu().to(tdt).float()
