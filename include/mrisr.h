@@ -269,6 +269,40 @@ int mrisr_adam_step_amp(float* p, const float* g, float* m, float* v, size_t n, 
 /* ---- layout helpers ----------------------------------------------------------------------- */
 int mrisr_cast(int src_dtype, const void* src, int dst_dtype, void* dst, size_t n, void* stream);
 
+/* ---- inference pre / post-processing on the device (scripts/infer.py:97-130, 276, 331) ---- */
+/* hist[batch][256] += histogram of batch 8-bit images of pixels_per_image bytes each (zero it first).               */
+int mrisr_u8_histogram(const uint8_t* img, size_t pixels_per_image, int batch, unsigned* hist, void* stream);
+/* out[b][i] = (clip(img[b][i], lo_b, hi_b) - lo_b) / (hi_b - lo_b) with lo_b / hi_b = np.percentile(img[b], q_lo / q_hi)
+ * (method 'linear', numpy's float32 arithmetic); unnormalised clipped values when hi_b <= lo_b (infer.py:115-117).
+ * lohi (optional) receives [batch][2] = (lo_b, hi_b).                                                                */
+int mrisr_u8_percentile_normalise(const uint8_t* img, const unsigned* hist, size_t pixels_per_image, int batch,
+                                  double q_lo, double q_hi, float* out, float* lohi, void* stream);
+/* out[i] = (uint8)(clamp(x[i], 0, 1) * 255), truncating like ndarray.astype(np.uint8) (infer.py:276, 331).          */
+int mrisr_f32_to_u8(const float* x, uint8_t* out, size_t n, void* stream);
+
+/* ---- paired augmentation on the device (utils/dataset.py:138-175) ------------------------- */
+typedef struct {
+    float cos_a, sin_a;   /* of PIL's inverse rotation angle -radians(angle_degrees)                                  */
+    int32_t rotate;       /* 0: no rotation                                                                            */
+    int32_t flip;         /* horizontal flip first (TF.hflip), then the rotation                                       */
+    int32_t fill;         /* rotation fill value = int(mean of the un-augmented image) (dataset.py:152-155)            */
+    float brightness;     /* ImageEnhance.Brightness factor, 1 = none                                                  */
+} mrisr_aug_geo;
+typedef struct {
+    float contrast;       /* ImageEnhance.Contrast factor, 1 = none                                                    */
+    int32_t mean;         /* int(mean + 0.5) of the image entering the contrast stage                                  */
+    float noise_sigma;    /* Gaussian noise in uint8 units (dataset.py:169-172: noise_std * 255), 0 = none             */
+    uint32_t seed;        /* per-sample seed of the counter-based noise generator                                      */
+} mrisr_aug_photo;
+/* out[b] = brightness(rotate(flip(in[b]))) as uint8, PIL's NEAREST / truncation semantics; params: batch structs on the
+ * device.  mean_device (optional, [batch] doubles): per-image means kept on the device - fill = int(mean[b]) then
+ * overrides params[b].fill, so that no statistic has to be read back by the host.                                     */
+int mrisr_augment_geo_u8(const uint8_t* in, uint8_t* out, int batch, int H, int W, const mrisr_aug_geo* params_device,
+                         const double* mean_device, void* stream);
+/* out[b] = ToTensor(noise(contrast(in[b]))) as fp32 in [0,1]; mean_device (optional): mean = int(mean[b] + 0.5).      */
+int mrisr_augment_finish_u8(const uint8_t* in, float* out, int batch, size_t pixels_per_image,
+                            const mrisr_aug_photo* params_device, const double* mean_device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,15 @@ class PackJob(C.Structure):
                 ("transpose_flip", C.c_int32)]
 
 
+class AugGeo(C.Structure):
+    _fields_ = [("cos_a", C.c_float), ("sin_a", C.c_float), ("rotate", C.c_int32), ("flip", C.c_int32),
+                ("fill", C.c_int32), ("brightness", C.c_float)]
+
+
+class AugPhoto(C.Structure):
+    _fields_ = [("contrast", C.c_float), ("mean", C.c_int32), ("noise_sigma", C.c_float), ("seed", C.c_uint32)]
+
+
 class Consumer(C.Structure):
     _fields_ = [("da", _vp), ("C_total", C.c_int32), ("c_off", C.c_int32), ("H", C.c_int32),
                 ("W", C.c_int32), ("spatial", C.c_int32), ("off_y", C.c_int32), ("off_x", C.c_int32),
@@ -82,6 +91,11 @@ SIGNATURES = {
     "mrisr_feature_loss": (_i, [_i, _vp, _vp, _sz, _i, _dp, _fp, _vp, _i, _vp]),
     "mrisr_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "mrisr_adam_step_amp": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _vp, _f, _fp, _fp, _vp]),
+    "mrisr_u8_histogram": (_i, [_vp, _sz, _i, _vp, _vp]),
+    "mrisr_u8_percentile_normalise": (_i, [_vp, _vp, _sz, _i, _d, _d, _fp, _fp, _vp]),
+    "mrisr_f32_to_u8": (_i, [_fp, _vp, _sz, _vp]),
+    "mrisr_augment_geo_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _dp, _vp]),
+    "mrisr_augment_finish_u8": (_i, [_vp, _fp, _i, _sz, _vp, _dp, _vp]),
     "mrisr_cast": (_i, [_i, _vp, _i, _vp, _sz, _vp]),
 }
 

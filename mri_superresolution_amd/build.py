@@ -17,12 +17,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "mrisr")
 LIB = os.path.join(HERE, "libmrisr.so")
-SOURCES = ["api.cpp", "conv_fwd.hip", "conv_wgrad.hip", "norm.hip", "head_stem.hip", "loss.hip", "optim.hip", "vgg.hip"]
+SOURCES = ["api.cpp", "conv_fwd.hip", "conv_wgrad.hip", "norm.hip", "head_stem.hip", "loss.hip", "optim.hip", "vgg.hip", "image.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # conv_fwd.hip: no SLP vectorisation - it turns the epilogue's statistics into v_pk_*_f32 ops plus register shuffles, and
 # packed fp32 ops issue at half speed next to the other wave's MFMA block (measured with the phase profile)
-FILE_FLAGS = {"conv_fwd.hip": ["-fno-slp-vectorize"]}
+# image.hip: no fma contraction - it restates numpy / PIL float32 arithmetic operation by operation (HIP's __fmul_rn /
+# __fadd_rn are plain operators, and under the default -ffp-contract=fast  a + alpha * (b - a)  becomes one fma: PIL's
+# (UINT8) truncation then lands one grey level lower whenever the product is an integer minus 2^-22)
+FILE_FLAGS = {"conv_fwd.hip": ["-fno-slp-vectorize"], "image.hip": ["-ffp-contract=off"]}
 
 
 def _deps_mtime():

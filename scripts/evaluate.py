@@ -111,7 +111,7 @@ def find_pairs(full_res_dir: str, low_res_dir: str):
 def _load01(path: str) -> np.ndarray:
     """As the reference's evaluate.py: percentile-normalise (infer.preprocess_image), then through uint8."""
     from scripts.infer import preprocess_image
-    a = preprocess_image(path)[1].squeeze().numpy()
+    a = preprocess_image(path)[1].squeeze().cpu().numpy()
     return (a * 255).astype(np.uint8).astype(np.float32) / 255.0
 
 

@@ -1,13 +1,24 @@
 #!/usr/bin/env python3
 """Inference driver, MI355X-native mirror of ``/root/reference/scripts/infer.py`` (same flags, checkpoint
 search order, percentile pre-processing, clamp, optional histogram matching to the target, SSIM/RMSE/MAE
-metrics, uint8 PNG output, exit code 0 / 1).  The forward pass runs in the HIP kernels; ``--cpu`` is accepted
-for CLI compatibility and fails loudly.  ``--show_comparison`` saves the comparison PNG next to the output
-(no interactive window in this build)."""
+metrics, uint8 PNG output, exit code 0 / 1).
+
+Everything between the decoded PNG bytes and the encoded PNG bytes runs on the GPU: percentile clip + rescale
+(``utils/imageops.normalise_percentile_u8``: 256-bin histogram + look-up table kernels), the forward pass (HIP
+kernels, optionally one HIP-graph replay per batch), clamp + uint8 conversion, histogram matching and the metrics.
+``--cpu`` is accepted for CLI compatibility and fails loudly.
+
+Extension: ``--input`` may be a DIRECTORY - every ``*.png`` in it is enhanced into the
+``--output`` directory (same file names), in batches of ``--batch_size`` images of equal size, with PNG decode / encode
+on a small thread pool overlapped with the GPU work; ``--target`` may then be a directory of same-named references.
+``--show_comparison`` / ``--show_diff`` save ``<output>_comparison.png`` / ``<output>_diff.png`` (no interactive
+window in this build; the reference opens matplotlib windows, infer.py:337-394).
+"""
 import argparse
 import logging
 import os
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -17,6 +28,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from mri_superresolution_amd.models.unet_model import UNetSuperRes   # noqa: E402
+from mri_superresolution_amd.utils import imageops                   # noqa: E402
 from mri_superresolution_amd.utils.losses import SSIM                 # noqa: E402
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
@@ -51,6 +63,8 @@ def find_best_checkpoint(checkpoint_dir, model_type):
     raise FileNotFoundError(f"No checkpoint found for {model_type} model in {checkpoint_dir}")
 
 
+# ---------------------------------------------------------------------------------------------- numpy restatements
+# (what the reference computes on the host; kept as the specification the device path is tested against)
 def normalise_percentile(a: np.ndarray) -> np.ndarray:
     """clip to [p0.5, p99.5] then scale to [0,1] (reference infer.py:107-117)."""
     lo, hi = np.percentile(a, 0.5), np.percentile(a, 99.5)
@@ -58,17 +72,7 @@ def normalise_percentile(a: np.ndarray) -> np.ndarray:
     return (a - lo) / (hi - lo) if hi > lo else a
 
 
-def preprocess_image(image_path):
-    from PIL import Image
-    image = Image.open(image_path).convert("L")
-    a = normalise_percentile(np.array(image).astype(np.float32)).astype(np.float32)
-    h, w = a.shape
-    if h % 8 or w % 8:
-        logger.warning(f"Input image dimensions ({h}x{w}) are not divisible by 8.")
-    return image, torch.from_numpy(a).unsqueeze(0).unsqueeze(0)
-
-
-def match_histograms(image: np.ndarray, reference: np.ndarray) -> np.ndarray:
+def match_histograms_np(image: np.ndarray, reference: np.ndarray) -> np.ndarray:
     """skimage.exposure.match_histograms for one channel: map each source value to the reference value of
     equal empirical CDF (rank/CDF + np.interp)."""
     src_vals, src_idx, src_counts = np.unique(image.ravel(), return_inverse=True, return_counts=True)
@@ -78,59 +82,165 @@ def match_histograms(image: np.ndarray, reference: np.ndarray) -> np.ndarray:
     return np.interp(src_q, ref_q, ref_vals)[src_idx].reshape(image.shape)
 
 
-def postprocess_tensor(t):
+# ---------------------------------------------------------------------------------------------- device path
+def load_gray_u8(image_path):
+    """PNG -> (PIL image, uint8 HxW array); the decode is the only host-side image work."""
     from PIL import Image
-    a = t.squeeze().detach().float().cpu().numpy()
-    return Image.fromarray((a * 255).astype(np.uint8))
+    image = Image.open(image_path).convert("L")
+    a = np.asarray(image, dtype=np.uint8)
+    h, w = a.shape
+    if h % 8 or w % 8:
+        logger.warning(f"Input image dimensions ({h}x{w}) are not divisible by 8. This might affect performance or "
+                       "spatial accuracy due to model pooling layers.")
+    return image, a
+
+
+def preprocess_image(image_path, device="cuda"):
+    """(PIL image, (1,1,H,W) fp32 tensor on the GPU) - reference infer.py:97-130 with the arithmetic on the device."""
+    image, a = load_gray_u8(image_path)
+    x = imageops.normalise_percentile_u8(torch.from_numpy(a.copy()).to(device, non_blocking=True))
+    return image, x
+
+
+def postprocess_tensor(t):
+    """[0,1] tensor (any of (H,W), (1,H,W), (1,1,H,W)) on the GPU -> PIL image, ``(x*255).astype(uint8)`` on the device."""
+    from PIL import Image
+    return Image.fromarray(imageops.to_uint8(t.squeeze()).cpu().numpy())
 
 
 def calculate_metrics(output, target):
+    """SSIM / RMSE / MAE (reference infer.py:148-171), reduced on the device, read back once."""
     if output.dim() == 3:
         output = output.unsqueeze(0)
     if target.dim() == 3:
         target = target.unsqueeze(0)
     m = {}
     try:
-        m["ssim"] = SSIM(window_size=11, sigma=1.5, val_range=1.0)(output, target).item()
-        d = (output.float() - target.float())
-        m["rmse"] = float(np.sqrt((d * d).mean().item()))
-        m["mae"] = float(d.abs().mean().item())
+        s = SSIM(window_size=11, sigma=1.5, val_range=1.0)(output, target)
+        d = output.float() - target.float()
+        vals = torch.stack([s.reshape(()).float(), (d * d).mean().sqrt(), d.abs().mean()]).tolist()
+        m["ssim"], m["rmse"], m["mae"] = (float(v) for v in vals)
     except Exception as e:
         logger.error(f"Error calculating metrics: {e}")
     return m
 
 
-def process_single_image(model, input_path, output_path, target_path=None, device="cuda", show_comparison=False,
-                         show_diff=False, use_amp=False):
-    input_image, x = preprocess_image(input_path)
-    x = x.to(device)
-    target = target_img = None
-    if target_path:
-        target_img, target = preprocess_image(target_path)
-        target = target.to(device)
+def enhance_batch(model, x, use_amp=False):
+    """(B,1,H,W) normalised input -> clamped (B,1,2H,2W) output (reference infer.py:268-276)."""
     model.set_compute_dtype(torch.float16 if use_amp else torch.float32)   # reference: torch.amp.autocast("cuda") = fp16
     with torch.no_grad():
-        out = model(x).clamp(0.0, 1.0)
-    metrics = None
-    if target is not None:
-        if out.shape[-2:] != target.shape[-2:]:      # reference infer.py:317-324
-            target = torch.nn.functional.interpolate(target, size=out.shape[-2:], mode="bicubic", align_corners=False)
-        o = match_histograms(out.squeeze().cpu().numpy(), target.squeeze().cpu().numpy())
-        out = torch.from_numpy(np.clip(o, 0, 1).astype(np.float32)).view_as(out).to(device)
-        metrics = calculate_metrics(out, target.clamp(0, 1))
-        logger.info("Metrics: " + ", ".join(f"{k.upper()}={v:.4f}" for k, v in metrics.items()))
-    os.makedirs(os.path.dirname(os.path.abspath(output_path)), exist_ok=True)
-    out_img = postprocess_tensor(out)
-    out_img.save(output_path)
-    logger.info(f"Saved output image to {output_path}")
+        return model(x).clamp_(0.0, 1.0)
+
+
+def adjust_to_target(out, target_norm):
+    """Histogram matching of one output plane to the normalised target + clip (reference infer.py:285-313)."""
+    try:
+        return imageops.match_histograms(out, target_norm).clamp_(0.0, 1.0).to(torch.float32)
+    except Exception as e:        # reference: "Error during histogram matching ... Using raw model output."
+        logger.error(f"Error during histogram matching: {e}. Using raw model output.")
+        return out
+
+
+def _save_side_products(out_img, input_image, target_img, output_path, show_comparison, show_diff):
+    from PIL import Image
+    stem = os.path.splitext(output_path)[0]
     if show_comparison:
-        from PIL import Image
         tiles = [input_image.resize(out_img.size), out_img] + ([target_img.resize(out_img.size)] if target_img else [])
         canvas = Image.new("L", (out_img.size[0] * len(tiles), out_img.size[1]))
         for i, tl in enumerate(tiles):
             canvas.paste(tl, (i * out_img.size[0], 0))
-        canvas.save(os.path.splitext(output_path)[0] + "_comparison.png")
+        canvas.save(stem + "_comparison.png")
+    if show_diff and target_img is not None:      # reference infer.py:358-392: |output - target| of the uint8 images
+        tgt = target_img if target_img.size == out_img.size else target_img.resize(out_img.size, Image.BICUBIC)
+        diff = np.abs(np.asarray(out_img, dtype=np.float32) - np.asarray(tgt, dtype=np.float32))
+        Image.fromarray(diff.astype(np.uint8)).save(stem + "_diff.png")
+
+
+def process_single_image(model, input_path, output_path, target_path=None, device="cuda", show_comparison=False,
+                         show_diff=False, use_amp=False):
+    input_image, x = preprocess_image(input_path, device)
+    target = target_img = None
+    if target_path:
+        target_img, target = preprocess_image(target_path, device)
+    out = enhance_batch(model, x, use_amp)
+    adjusted, metrics = out, None
+    if target is not None:
+        adjusted = adjust_to_target(out[0, 0], target[0, 0])          # reference: matched against the target at ITS size
+        t_m = target
+        if out.shape[-2:] != t_m.shape[-2:]:                          # reference infer.py:317-324
+            logger.warning(f"Target shape {tuple(t_m.shape[-2:])} differs from output shape {tuple(out.shape[-2:])}. "
+                           "Resizing target for metrics calculation using bicubic interpolation.")
+            t_m = torch.nn.functional.interpolate(t_m, size=out.shape[-2:], mode="bicubic", align_corners=False)
+        metrics = calculate_metrics(out, t_m)                         # on the raw clamped output, as the reference
+        for k, v in metrics.items():
+            logger.info(f"{k.upper()}: {v:.4f}")
+    os.makedirs(os.path.dirname(os.path.abspath(output_path)), exist_ok=True)
+    out_img = postprocess_tensor(adjusted)
+    out_img.save(output_path)
+    logger.info(f"Enhanced image saved to {output_path}")
+    _save_side_products(out_img, input_image, target_img, output_path, show_comparison, show_diff)
     return out_img, metrics
+
+
+def process_directory(model, input_dir, output_dir, target_dir=None, device="cuda", use_amp=False, batch_size=16,
+                      workers=8, use_graph=True):
+    """Batch mode: every PNG of ``input_dir`` -> ``output_dir``.  Images are grouped by size; a group is run in batches of
+    ``batch_size`` (the eval forward of a full batch shape is captured once as a HIP graph and replayed).  Decode and
+    encode run on ``workers`` threads, uploads / downloads through pinned buffers, so the GPU is not waiting for PIL.
+    Returns {file name: metrics or None}."""
+    from PIL import Image
+    names = sorted(f for f in os.listdir(input_dir) if f.lower().endswith(".png"))
+    if not names:
+        raise FileNotFoundError(f"no PNG files in {input_dir}")
+    os.makedirs(output_dir, exist_ok=True)
+    results = {}
+    graphs = {}
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+        decoded = list(pool.map(lambda f: np.asarray(Image.open(os.path.join(input_dir, f)).convert("L"), dtype=np.uint8), names))
+        groups = {}
+        for f, a in zip(names, decoded):
+            groups.setdefault(a.shape, []).append((f, a))
+        saves = []
+        for (h, w), items in groups.items():
+            if h % 8 or w % 8:
+                logger.warning(f"{len(items)} image(s) of {h}x{w}: dimensions not divisible by 8.")
+            for i0 in range(0, len(items), batch_size):
+                chunk = items[i0:i0 + batch_size]
+                host = torch.from_numpy(np.stack([a for _, a in chunk])).pin_memory()
+                x = imageops.normalise_percentile_u8(host.to(device, non_blocking=True))
+                model.set_compute_dtype(torch.float16 if use_amp else torch.float32)
+                key = (tuple(x.shape), use_amp)
+                if use_graph and len(chunk) == batch_size:
+                    if key not in graphs:
+                        graphs[key] = model.graphed_forward(x)
+                    out = graphs[key](x).clamp(0.0, 1.0)
+                else:
+                    out = enhance_batch(model, x, use_amp)
+                adjusted = out
+                metrics = [None] * len(chunk)
+                if target_dir:
+                    adjusted = out.clone()
+                    for j, (f, _) in enumerate(chunk):
+                        tp = os.path.join(target_dir, f)
+                        if not os.path.exists(tp):
+                            continue
+                        _, t = preprocess_image(tp, device)
+                        adjusted[j, 0] = adjust_to_target(out[j, 0], t[0, 0])
+                        if out.shape[-2:] != t.shape[-2:]:
+                            t = torch.nn.functional.interpolate(t, size=out.shape[-2:], mode="bicubic", align_corners=False)
+                        metrics[j] = calculate_metrics(out[j:j + 1], t)
+                u8 = imageops.to_uint8(adjusted[:, 0]).cpu().numpy()
+                for j, (f, _) in enumerate(chunk):
+                    results[f] = metrics[j]
+                    saves.append(pool.submit(lambda a, p: Image.fromarray(a).save(p), u8[j], os.path.join(output_dir, f)))
+        for s in saves:
+            s.result()
+    logger.info(f"Enhanced {len(names)} image(s) from {input_dir} into {output_dir}")
+    scored = [m for m in results.values() if m]
+    if scored:
+        logger.info("Mean over %d scored images: " % len(scored)
+                    + ", ".join(f"{k.upper()}={np.mean([m[k] for m in scored]):.4f}" for k in scored[0]))
+    return results
 
 
 def main(args):
@@ -138,10 +248,23 @@ def main(args):
         if args.cpu or not torch.cuda.is_available():
             raise RuntimeError("this build runs on MI355X only (hand-written HIP kernels, no CPU fallback)")
         device = torch.device("cuda")
-        ckpt = args.checkpoint_path or find_best_checkpoint(args.checkpoint_dir, args.model_type)
+        logger.info(f"Using device: {device} ({torch.cuda.get_device_name(0)})")
+        if args.use_amp:
+            logger.info("Using Automatic Mixed Precision (AMP) for inference.")
+        if args.checkpoint_path and os.path.exists(args.checkpoint_path):
+            ckpt = args.checkpoint_path
+            logger.info(f"Using specified checkpoint: {ckpt}")
+        else:
+            ckpt = find_best_checkpoint(args.checkpoint_dir, args.model_type)
+            logger.info(f"Automatically selected checkpoint: {ckpt}")
         model = load_model(args.model_type, ckpt, device, base_filters=args.base_filters)
-        process_single_image(model, args.input, args.output, args.target, device, args.show_comparison,
-                             args.show_diff, args.use_amp)
+        if os.path.isdir(args.input):
+            process_directory(model, args.input, args.output, args.target, device, args.use_amp, args.batch_size,
+                              args.io_workers, not args.no_graph)
+        else:
+            process_single_image(model, args.input, args.output, args.target, device, args.show_comparison,
+                                 args.show_diff, args.use_amp)
+        logger.info("Inference completed successfully!")
         return 0
     except Exception as e:
         logger.error(f"Error during inference: {e}")
@@ -150,9 +273,9 @@ def main(args):
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="MRI quality enhancement inference")
-    p.add_argument("--input", type=str, required=True)
-    p.add_argument("--output", type=str, required=True)
-    p.add_argument("--target", type=str, default=None)
+    p.add_argument("--input", type=str, required=True, help="Input PNG (or, extension: a directory of PNGs)")
+    p.add_argument("--output", type=str, required=True, help="Output PNG (or output directory in batch mode)")
+    p.add_argument("--target", type=str, default=None, help="Optional reference PNG (or directory of same-named PNGs)")
     p.add_argument("--checkpoint_dir", type=str, default="./checkpoints")
     p.add_argument("--checkpoint_path", type=str, default=None)
     p.add_argument("--model_type", type=str, choices=["unet"], default="unet")
@@ -161,6 +284,9 @@ def parse_args(argv=None):
     p.add_argument("--show_diff", action="store_true")
     p.add_argument("--cpu", action="store_true", help="accepted for CLI compatibility; not supported (GPU-only build)")
     p.add_argument("--use_amp", action="store_true", help="fp16 MFMA compute (the reference's autocast)")
+    p.add_argument("--batch_size", type=int, default=16, help="(extension) images per forward in directory mode")
+    p.add_argument("--io_workers", type=int, default=8, help="(extension) PNG decode / encode threads in directory mode")
+    p.add_argument("--no_graph", action="store_true", help="(extension) directory mode: do not replay the forward as a HIP graph")
     return p.parse_args(argv)
 
 

@@ -149,8 +149,15 @@ def train(args):
     n_train = len(dataset) - n_val
     perm = torch.randperm(len(dataset), generator=torch.Generator().manual_seed(args.seed)).tolist()
     train_idx, val_idx = perm[:n_train], perm[n_train:]
-    val_loader = make_loader(dataset, val_idx[rank::world] if world > 1 else val_idx, args.batch_size,
-                             args.num_workers, False, args.seed) if n_val > 0 else None
+    val_ids = val_idx[rank::world] if world > 1 else val_idx
+    train_dev_loader = None
+    if args.gpu_data:
+        from mri_superresolution_amd.utils.gpu_augment import DevicePairLoader
+        log_message("Data pipeline: uint8 pairs resident in HBM, batches gathered and augmented on the device.")
+        val_loader = DevicePairLoader(dataset, args.batch_size, val_ids, shuffle=False, augmentation=False, seed=args.seed,
+                                      device=device, io_workers=max(1, args.num_workers)) if val_ids else None
+    else:
+        val_loader = make_loader(dataset, val_ids, args.batch_size, args.num_workers, False, args.seed) if n_val > 0 else None
 
     criterion = CombinedLoss(ssim_weight=args.ssim_weight, perceptual_weight=args.perceptual_weight,
                              vgg_layer_idx=args.vgg_layer_idx, perceptual_loss_type=args.perceptual_loss_type,
@@ -180,7 +187,15 @@ def train(args):
         model.train()
         idx = [train_idx[i] for i in shard_indices(n_train, rank, world, epoch, True, args.seed)] if world > 1 \
             else train_idx
-        loader = make_loader(dataset, idx, args.batch_size, args.num_workers, True, args.seed + epoch)
+        if args.gpu_data:
+            if train_dev_loader is None or world > 1:      # (data parallel: the rank's shard changes with the epoch)
+                train_dev_loader = DevicePairLoader(dataset, args.batch_size, idx, shuffle=True,
+                                                    augmentation=args.augmentation, seed=args.seed + rank,
+                                                    device=device, io_workers=max(1, args.num_workers))
+            train_dev_loader.set_epoch(epoch)
+            loader = train_dev_loader
+        else:
+            loader = make_loader(dataset, idx, args.batch_size, args.num_workers, True, args.seed + epoch)
         acc = torch.zeros(3, device=device)          # running sums stay on the device: no per-batch host sync
         for batch_idx, (low, high) in enumerate(loader):
             low, high = low.to(device, non_blocking=True), high.to(device, non_blocking=True)
@@ -297,6 +312,9 @@ def parse_args(argv=None):
     p.add_argument("--augmentation", action="store_true")
     p.add_argument("--use_tensorboard", action="store_true")
     p.add_argument("--use_amp", action="store_true", help="Use Automatic Mixed Precision training (fp16 autocast + GradScaler)")
+    p.add_argument("--gpu_data", action="store_true",
+                   help="(extension) keep the uint8 slice pairs resident in HBM and assemble / augment every batch on the "
+                        "device (utils/gpu_augment.DevicePairLoader) instead of DataLoader workers + PIL")
     p.add_argument("--amp_dtype", type=str, default="fp16", choices=["fp16", "bf16"],
                    help="(extension) autocast dtype of --use_amp: fp16 as the reference, or bf16 without loss scaling")
     p.add_argument("--cpu", action="store_true", help="accepted for CLI compatibility; not supported (GPU-only build)")

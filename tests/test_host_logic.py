@@ -129,7 +129,7 @@ def test_cli_flags_match_reference():
     y = infer.normalise_percentile(x)
     assert y.min() == 0.0 and y.max() == 1.0
     src, ref = np.array([[0.1, 0.2], [0.3, 0.4]]), np.array([[1.0, 2.0], [3.0, 4.0]])
-    assert np.allclose(infer.match_histograms(src, ref), ref)
+    assert np.allclose(infer.match_histograms_np(src, ref), ref)
 
 
 def test_shard_indices_cover_dataset():
