@@ -89,6 +89,10 @@ typedef struct {
     const void* relu_mask;  /* NULL, or a tensor shaped like out: out is zeroed where relu_mask <= 0 (the ReLU
                                backward of the frozen VGG19 stack, utils/losses.py:95,145: this conv computes
                                dL/d(relu output), relu_mask = that relu output); 3x3, plain source/output only */
+    int32_t cu_limit;       /* 0 = size the persistent grid for every CU of the device; k > 0: for k CUs only - for
+                               launches that are meant to run BESIDE another stream's kernels (the weight gradients of
+                               the backward pass next to the gradient chain) without either waiting for the other's CUs */
+    int32_t reserved_;
 } mrisr_conv_desc;
 
 const char* mrisr_last_error(void);

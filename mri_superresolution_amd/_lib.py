@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("Cin", C.c_int32), ("Cout", C.c_int32), ("ksize", C.c_int32), ("nsrc", C.c_int32),
                 ("combine", C.c_int32), ("out_mode", C.c_int32), ("groups", C.c_int32),
                 ("relu_out", C.c_int32), ("src", Src * 2), ("blend_alpha", _fp), ("wpacked", _vp),
-                ("bias", _fp), ("out", _vp), ("stats", _dp), ("relu_mask", _vp)]
+                ("bias", _fp), ("out", _vp), ("stats", _dp), ("relu_mask", _vp), ("cu_limit", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -139,6 +140,18 @@ def call(name: str, *args):
 def ptr(t):
     """Raw device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+_NUM_CUS = None
+
+
+def num_cus() -> int:
+    """Compute units of the current device (torch's device properties: plumbing)."""
+    global _NUM_CUS
+    if _NUM_CUS is None:
+        import torch
+        _NUM_CUS = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+    return _NUM_CUS
 
 
 def stream_ptr():

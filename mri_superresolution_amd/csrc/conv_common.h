@@ -92,6 +92,7 @@ struct ConvParams {
     int ksplit;       // wgrad only
     int ws;           // forward: all cin chunks of the weight image stay resident in LDS
     int ntiles, tiles_per_block;   // forward: persistent blocks own contiguous tile ranges
+    int cus;          // CUs the persistent grid is sized for (mrisr_conv_desc.cu_limit, else all)
     int dbg;          // tuning builds only (-DMRISR_TUNING, env MRISR_DEBUG): 1 no stores, 2 no LDS commit, 4 no global loads, 8 no MFMA
 };
 // Ablation bits exist in tuning builds only (tools/build_prof.sh): the product library never reads the environment

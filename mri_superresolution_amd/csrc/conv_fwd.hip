@@ -1236,6 +1236,7 @@ extern "C" int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, 
 }
 
 // ------------------------------------------------------------------------------------------------
+int num_cus();
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
     if (!d) MRISR_FAIL(MRISR_E_ARG, "%s: null descriptor", who);
     if (!mrisr_dtype_ok(d->dtype)) MRISR_FAIL(MRISR_E_DTYPE, "%s: dtype %d", who, d->dtype);
@@ -1281,6 +1282,7 @@ int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who) {
     p.ncb = ceil_div(d->Cout, BN); p.CoutP = p.ncb * BN;
     p.nsrc = d->nsrc; p.combine = d->combine; p.out_mode = d->out_mode; p.groups = d->stats ? d->groups : 0;
     p.relu_out = d->relu_out;
+    p.cus = d->cu_limit > 0 && d->cu_limit < num_cus() ? d->cu_limit : num_cus();
 #ifdef MRISR_TUNING
     { static const int dbg_env = [] { const char* e = getenv("MRISR_DEBUG"); return e ? atoi(e) : 0; }(); p.dbg = dbg_env; }
 #endif
@@ -1320,7 +1322,7 @@ static int launch_conv_v(ConvParams& p, hipStream_t s) {
     p.ws = conv_weights_stationary(p.nchunks, wimg, DMA) ? 1 : 0;
     const size_t lds = conv_halo_total(DMA) + (p.ws ? p.nchunks : 2) * wimg + (BN + 128) * sizeof(float) + conv_stage_bytes();
     p.ntiles = p.N * p.tiles_y * p.tiles_x;
-    int per_cb = num_cus() / p.ncb;                     // persistent workgroups per cout block, one per CU
+    int per_cb = p.cus / p.ncb;                         // persistent workgroups per cout block, one per CU
     if (per_cb < 1) per_cb = 1;
     const int pairs = ceil_div(p.ntiles, 2);
     if (per_cb > pairs) per_cb = pairs;

@@ -463,7 +463,7 @@ int num_cus();
 static void wgrad_grid(const ConvParams& p, int BC, int& nblk, int& ksplit) {
     nblk = ceil_div(p.Cout, BC) * ceil_div(p.Cin, BC);
     const int total_tiles = p.N * p.tiles_y * p.tiles_x;
-    ksplit = ceil_div(num_cus(), nblk);          // one 8-wave workgroup per CU (LDS-limited)
+    ksplit = ceil_div(p.cus > 0 ? p.cus : num_cus(), nblk);          // one 8-wave workgroup per CU (LDS-limited)
     if (ksplit > total_tiles) ksplit = total_tiles;
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 65535) ksplit = 65535;

@@ -36,6 +36,15 @@ def _dt(dtype: torch.dtype) -> int:
 
 # order of the two convolutions of a layer's backward step (tuning: MRISR_WGRAD_LAST=1 runs dgrad first)
 _WGRAD_LAST = os.environ.get("MRISR_WGRAD_LAST", "0") == "1"
+# weight-gradient kernels on a second HIP stream (they hang off the backward chain: nothing downstream reads dW before the
+# optimiser step), so that they fill the launch-boundary gaps and memory-bound stretches of the main stream
+# (measured at C2 on one box, A/B alternating: one stream 9.70 ms/step; second stream, every kernel sized for the whole
+# chip 9.52; second stream + half the CUs each 9.31 (64 CUs for the weight gradients: 10.8, 96: 9.35, 144: 9.36-9.49,
+# 160: 9.58, 192: 10.8) - MRISR_WGRAD_STREAM=0 / MRISR_WGRAD_CUS=k override for A/B runs)
+_WGRAD_STREAM = os.environ.get("MRISR_WGRAD_STREAM", "1") == "1"
+# CUs given to the second stream's weight-gradient kernels; the backward chain's convolutions are sized for the rest
+# (0 = no split: every persistent kernel is sized for the whole chip and the two streams take turns; -1 = half)
+_WGRAD_CUS = int(os.environ.get("MRISR_WGRAD_CUS", "-1"))
 
 
 @dataclass
@@ -464,6 +473,28 @@ class UNetEngine:
         if bucket_hook:
             bucket_hook("final_conv.3")
 
+        # second stream for the weight gradients (not while kernels are being timed with events on the main stream)
+        side = None
+        main = torch.cuda.current_stream()
+        side_cus = L.num_cus() // 2 if _WGRAD_CUS < 0 else _WGRAD_CUS
+        if _WGRAD_STREAM and self.timer is None:
+            side = getattr(self, "_side_stream", None)
+            if side is None or side.device != dev:
+                # high priority = its own hardware queue class: with RCCL's streams around, a normal-priority second
+                # stream was mapped onto the main stream's hardware queue (GPU_MAX_HW_QUEUES = 4 by default) and the
+                # cross-stream waits serialised the step (measured 12.0 instead of 9.5 ms under data parallelism)
+                side = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MRISR_SIDE_PRIO", "-1")))
+        user_hook = bucket_hook
+        if bucket_hook is not None and side is not None:
+            def bucket_hook(name):     # noqa: F811
+                # data parallel: a layer's bucket may go out once its dW (second stream) AND everything the main stream
+                # has written into the flat gradient so far are complete: the collective is enqueued from the second
+                # stream after it has waited for the main stream's current position
+                ev2 = torch.cuda.Event()
+                ev2.record(main)
+                side.wait_event(ev2)
+                with torch.cuda.stream(side):
+                    user_hook(name)
         for layer in reversed(self.layers):
             o = layer.out
             # pixel-shuffle conv with bias: its bias gradient (channel sums of dy) comes out of the un-shuffling pass
@@ -479,9 +510,18 @@ class UNetEngine:
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self._wgrad_ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
             def launch_wgrad():
-                self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
-                                                        grads[layer.name + ".weight"].data_ptr(), ws.data_ptr(),
-                                                        ws.numel(), st))
+                if side is None:
+                    self._launch("wgrad", d, lambda: L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(),
+                                                            grads[layer.name + ".weight"].data_ptr(), ws.data_ptr(),
+                                                            ws.numel(), st))
+                    return
+                ev = torch.cuda.Event()
+                ev.record(main)                      # dy (and everything queued before it) is ready
+                side.wait_event(ev)
+                d.cu_limit = side_cus
+                L.call("mrisr_conv_wgrad", C.byref(d), dy.data_ptr(), grads[layer.name + ".weight"].data_ptr(),
+                       ws.data_ptr(), ws.numel(), side.cuda_stream)
+                dy.record_stream(side)               # the caching allocator must not hand dy's block out early
             wgrad_last = _WGRAD_LAST
             if not wgrad_last:
                 launch_wgrad()
@@ -499,6 +539,8 @@ class UNetEngine:
             dd.wpacked = self._packed[(layer.name, dt, 1)].data_ptr()
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
+            if side is not None and side_cus > 0:
+                dd.cu_limit = max(8, L.num_cus() - side_cus)
             self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))
             if wgrad_last:
                 launch_wgrad()
@@ -528,6 +570,9 @@ class UNetEngine:
                N, self.stem.H, self.stem.W, self.f, st)
         if bucket_hook:
             bucket_hook("inc.double_conv.0")
+        if side is not None:
+            main.wait_stream(side)                   # every dW is complete before the optimiser (and before the saved
+                                                     # activations the side stream was reading are released below)
         for n in self.nodes.values():
             n.raw = n.scale = n.shift = n.meanrstd = n.stats = None
             n.consumers = []

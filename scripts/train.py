@@ -18,8 +18,10 @@ import random
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # two compute streams + RCCL's on separate hardware queues (before HIP starts)
+
+import torch                                           # noqa: E402
+import torch.distributed as dist                       # noqa: E402
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
