@@ -45,6 +45,9 @@ _WGRAD_STREAM = os.environ.get("MRISR_WGRAD_STREAM", "1") == "1"
 # CUs given to the second stream's weight-gradient kernels; the backward chain's convolutions are sized for the rest
 # (0 = no split: every persistent kernel is sized for the whole chip and the two streams take turns; -1 = half)
 _WGRAD_CUS = int(os.environ.get("MRISR_WGRAD_CUS", "-1"))
+# (also tried: input gradient first on the whole chip, the weight gradient behind it on 128-224 CUs so that it overlaps the
+# next node's memory-bound GroupNorm-backward passes instead of the input gradient: 9.33-9.41 ms/step, no better than the
+# half / half split's 9.37-9.39 on the same box - the two kinds of kernel also compete for HBM and for the power budget)
 
 
 @dataclass

@@ -21,13 +21,14 @@ from . import _lib as L
 class FusedAdam(torch.optim.Optimizer):
     _step_supports_amp_scaling = True      # torch.amp.GradScaler.step: pass grad_scale / found_inf tensors, do not unscale
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, device_step=False):
         if not hasattr(model, "flat_params"):
             raise TypeError("FusedAdam needs a model with flat parameter storage (UNetSuperRes)")
         self.model = model
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step = 0
         self._step_dev = None           # int32 device counter, used from the first GradScaler-driven step on
+        self.device_step = bool(device_step)   # always count on the device (HIP-graph replay: graph_step.GraphedTrainStep)
         self.dp_grad_scale = 1.0        # 1/world_size when gradients were sum-all-reduced (data parallel)
         self._alloc()
 
@@ -56,7 +57,7 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         # torch.amp.GradScaler.step sets these two attributes (device tensors) around its call of step()
         loss_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
-        if loss_scale is not None or found_inf is not None or self._step_dev is not None:
+        if loss_scale is not None or found_inf is not None or self._step_dev is not None or self.device_step:
             if self._step_dev is None:      # first scaled step: the count moves to the device (skipped steps do not count)
                 self._step_dev = torch.tensor([self._step], dtype=torch.int32, device=m.flat_params.device)
             ls = None if loss_scale is None else loss_scale.detach().to(torch.float32).reshape(-1)
@@ -93,6 +94,11 @@ class FusedAdam(torch.optim.Optimizer):
         """Optimiser steps taken (reads the device counter back when a GradScaler drives the steps)."""
         return int(self._step_dev.item()) if self._step_dev is not None else self._step
 
+    def set_step_count(self, step: int):
+        self._step = int(step)
+        if self._step_dev is not None:
+            self._step_dev.fill_(int(step))
+
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
         n = len(self.param_groups[0]["params"])
@@ -117,6 +123,4 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 ea.copy_(ent["exp_avg"])
                 es.copy_(ent["exp_avg_sq"])
-                self._step = int(float(ent["step"]))
-                if self._step_dev is not None:
-                    self._step_dev.fill_(self._step)
+                self.set_step_count(int(float(ent["step"])))

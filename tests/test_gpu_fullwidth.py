@@ -289,3 +289,4 @@ def test_fused_adam_state_dict_round_trip():
     # torch.optim.Adam can read the same dict (layout compatibility)
     ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in a.parameters()]
     torch.optim.Adam(ref_params, lr=1e-3).load_state_dict(ck["opt"])
+
