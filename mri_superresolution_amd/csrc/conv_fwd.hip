@@ -918,51 +918,76 @@ __global__ __launch_bounds__(kFwdThreads, 2) void conv_igemm_kernel(const ConvPa
     // halo buffer c & 1 of its half and weight image c & 1; the DMAs for item c + 1 are issued after the barrier that
     // every wave passes once its MFMAs of item c - 1 (the last readers of those buffers) are done.
     if constexpr (DMA) {
-        int it_tile = tile0, it_kc = 0, it_n = 0, it_ty0 = 0, it_tx0 = 0;
-        const int nitems_wg = nh0 * p.nchunks;         // half 0 never has fewer tiles than half 1
-        if (nitems > 0) {
+        // Optional stagger (-DMRISR_STAGGER, tuning builds): half 1 runs ONE item behind half 0 - both halves use the same
+        // chunk per step (the streamed weight image is shared), so half 1's tiles take their chunks in the rotated order
+        // 1, 2, ..., n-1, 0 and its epilogues fall on the step after half 0's, while the SIMD's other wave runs MFMAs.
+        // Measured neutral in the training step (64-channel weights-stationary kernel 124.3 -> 125.8 us, streamed kernel
+        // 84.0 -> 84.6 us, A/B on one box): like the schedule variants before it - the loop is power-limited, what is on
+        // the SIMD at the same time does not matter.  Off by default.
+#ifdef MRISR_STAGGER
+        const int stag = (__builtin_amdgcn_readfirstlane(half) == 1 && p.nchunks >= 2) ? 1 : 0;
+        const int nitems1 = (nbt - nh0) * p.nchunks;              // half 1's items (workgroup-uniform)
+        const int total = max(nh0 * p.nchunks, nitems1 + ((nitems1 > 0 && p.nchunks >= 2) ? 1 : 0));
+#else
+        const int stag = 0;
+        const int total = nh0 * p.nchunks;                        // steps of the workgroup (half 0 never has fewer tiles)
+#endif
+        int it_tile = tile0, it_jj = 0, it_n = 0, it_ty0 = 0, it_tx0 = 0;     // current item of this half: tile, chunks done in it
+        int gkc = 0;                                                           // chunk of the current step (shared)
+        if (stag == 0 && nitems > 0) {
             decode(it_tile, it_n, it_ty0, it_tx0);
             issue_dma(it_n, 0, it_ty0, it_tx0, 0);
         }
         if constexpr (!WS) {
-            if (nitems_wg > 0) dma_weights(0, 0, std::integral_constant<int, 8>{});
+            if (total > 0) dma_weights(0, 0, std::integral_constant<int, 8>{});
         }
         PT_DECL
-        for (int c = 0; c < nitems_wg; ++c) {
+        for (int c = 0; c < total; ++c) {
             PT_MARK(8)
-            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's pieces of item c (and older stores) have landed
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's pieces of step c (and older stores) have landed
             PT_MARK(0)
             __syncthreads();
             PT_MARK(5)
-            int nx_kc = it_kc + 1, nx_tile = it_tile, nx_n = it_n, nx_ty0 = it_ty0, nx_tx0 = it_tx0;
-            if (nx_kc == p.nchunks) {
-                nx_kc = 0;
-                nx_tile = it_tile + 1;
-                if (nx_tile < tile1) decode(nx_tile, nx_n, nx_ty0, nx_tx0);
+            const int j = c - stag;                   // this half's item index at this step
+            const bool cur_valid = j >= 0 && j < nitems, nx_valid = j + 1 >= 0 && j + 1 < nitems;
+            int nx_kc = gkc + 1;
+            if (nx_kc == p.nchunks) nx_kc = 0;
+            int nx_jj = it_jj, nx_tile = it_tile, nx_n = it_n, nx_ty0 = it_ty0, nx_tx0 = it_tx0;
+            if (nx_valid) {
+                if (j + 1 == 0) {                     // half 1's first item
+                    nx_jj = 0;
+                    decode(nx_tile, nx_n, nx_ty0, nx_tx0);
+                } else if (++nx_jj == p.nchunks) {
+                    nx_jj = 0;
+                    nx_tile = it_tile + 1;
+                    decode(nx_tile, nx_n, nx_ty0, nx_tx0);
+                }
             }
             PT_MARK(2)
-            // plan of the next item's DMAs (addresses and validity of this thread's halo slots, this wave's weight
+            // plan of the next step's DMAs (addresses and validity of this thread's halo slots, this wave's weight
             // pieces); they are issued one per MFMA step by `pace`
             DmaPlan plan;
-            plan_dma(plan, nx_n, nx_kc, nx_ty0, nx_tx0, (c + 1) & 1, c + 1, c + 1 < nitems, c + 1 < nitems_wg);
+            plan_dma(plan, nx_n, nx_kc, nx_ty0, nx_tx0, (c + 1) & 1, c + 1, nx_valid, c + 1 < total);
             PT_MARK(3)
-            if (c < nitems) {
+            if (cur_valid) {
                 asm volatile("" : "+v"(wb));     // (see the antiphase schedule: keeps the 36 weight tap addresses out of VGPRs)
-                run_mma(lds_halo + (c & 1) * kDmaHaloBytes, lds_w + (size_t)(WS ? it_kc : (c & 1)) * (WIMG_VECS * 16),
+                run_mma(lds_halo + (c & 1) * kDmaHaloBytes, lds_w + (size_t)(WS ? gkc : (c & 1)) * (WIMG_VECS * 16),
                         [&](int st) { pace_dma(plan, st); });
                 PT_MARK(6)
-                if (it_kc == p.nchunks - 1) {
+                if (it_jj == p.nchunks - 1) {
                     epilogue(it_n, it_ty0, it_tx0);
                     PT_MARK(4)
-                    if (p.stats && (c + 1 >= nitems || nx_n != it_n)) flush_stats(it_n);
+                    if (p.stats && (!nx_valid || nx_n != it_n)) flush_stats(it_n);
                     PT_MARK(9)
                 }
             } else {
-                // this half has run out of tiles but still owes its share of the next weight image
+                // this half has no item at this step but still owes its DMAs (its share of the next weight image, its
+                // own next halo tile)
 #pragma unroll
                 for (int st = 0; st < 2 * NTAPS; ++st) pace_dma(plan, st);
             }
-            it_kc = nx_kc; it_tile = nx_tile; it_n = nx_n; it_ty0 = nx_ty0; it_tx0 = nx_tx0;
+            gkc = nx_kc;
+            it_jj = nx_jj; it_tile = nx_tile; it_n = nx_n; it_ty0 = nx_ty0; it_tx0 = nx_tx0;
         }
 #ifdef MRISR_PHASE_TIMING
         if (blockIdx.x == gridDim.x / 2 && lane == 0) {
