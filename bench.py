@@ -49,6 +49,8 @@ def parse():
                     help="BASELINE.json configs[2]: + VGG19 perceptual term (random-init VGG19: no weights offline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-forward-metric", action="store_true", help="skip the extra eval-forward timing (profiling runs: keeps "
+                                                                    "the per-step kernel / traffic totals free of its launches)")
     ap.add_argument("--forward-only", action="store_true", help="eval forward only (inference metric; not the headline)")
     ap.add_argument("--graph", action="store_true", help="with --forward-only: replay the forward as one HIP graph")
     return ap.parse_args()
@@ -284,7 +286,7 @@ def main():
         noex_elapsed = float(tt.item())
     # ---- forward-only metric (scripts/infer.py:268-276: eval forward, no_grad) in the same run, same batch
     fwd_elapsed, fwd_steps = None, 20
-    if not args.forward_only:
+    if not args.forward_only and not args.no_forward_metric:
         model.eval()
         for _ in range(3):
             fwd_step()
@@ -352,7 +354,12 @@ def main():
                                    "launches": dom["launches"], "us_per_launch": round(dom["ms_per_launch"] * 1e3, 2),
                                    "flops_per_launch": dom["flops_per_launch"],
                                    "timing": f"HIP events on the launch stream, separate pass of {timed_steps} steps "
-                                             f"({timed_elapsed / timed_steps * 1e3:.3f} ms/step instrumented)"}
+                                             f"({timed_elapsed / timed_steps * 1e3:.3f} ms/step instrumented), ONE stream, "
+                                             "every persistent kernel sized for the whole chip (the headline region runs "
+                                             "the weight gradients on a second stream, each kind on half the CUs); a "
+                                             "conv_wgrad entry = conv_wgrad_kernel + its wgrad_reduce_kernel (two-stage "
+                                             "split-K) timed as one unit; rocprofv3 counterpart: "
+                                             "profiles/r02_step_kernel_stats_single_stream.csv"}
                 table, prov = pmc_traffic()
                 rec["roofline"]["traffic_provenance"] = prov
                 if table is not None:

@@ -7,8 +7,8 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=/root/repo
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer $*"
-STEPS=8          # warm-up + timed (the forward-only metric's 23 eval forwards ride along and are folded per kernel)
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-forward-metric $*"
+STEPS=8          # warm-up + timed
 rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 $R/bench.py $ARGS > $R/gpurun_out/${tag}_kt.log 2>&1
 f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
