@@ -1,11 +1,12 @@
 """MI355X-native mirror of ``/root/reference/models/unet_model.py`` (same public names,
 constructor signatures and ``state_dict`` keys).
 
-The sub-modules below only HOLD parameters (so that ``named_parameters`` / ``state_dict`` /
-``load_state_dict`` / ``nn.init`` behave exactly as for the reference); all arithmetic of
-``UNetSuperRes.forward`` runs in hand-written HIP kernels scheduled by
-``mri_superresolution_amd.engine.UNetEngine``.  There is no CPU path: calling ``forward`` with a
-CPU tensor, or without the built ``libmrisr.so``, raises.
+Inside ``UNetSuperRes`` the sub-modules below only HOLD parameters (so that ``named_parameters`` /
+``state_dict`` / ``load_state_dict`` / ``nn.init`` behave exactly as for the reference); all arithmetic
+of ``UNetSuperRes.forward`` runs in hand-written HIP kernels scheduled by
+``mri_superresolution_amd.engine.UNetEngine``.  Called on their own, the blocks run the same kernels
+layer by layer (``mri_superresolution_amd.standalone``, inference only).  There is no CPU path: calling
+``forward`` with a CPU tensor, or without the built ``libmrisr.so``, raises.
 
 Parameter storage: all 64 tensors are views of ONE flat fp32 buffer (``model.flat_params``); conv
 weights are stored channels-last ([Cout][kh][kw][Cin]) which is what the kernels and the
@@ -21,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.init as init
 
+from .. import standalone
 from ..engine import UNetEngine
 
 
@@ -34,13 +36,7 @@ def icnr(w, scale=2, init_method=init.kaiming_normal_):
         w.copy_(sub.repeat_interleave(scale ** 2, dim=0))
 
 
-class _NoStandaloneForward(nn.Module):
-    def forward(self, *a, **k):
-        raise RuntimeError(f"{type(self).__name__} holds parameters only; it executes as part of "
-                           "UNetSuperRes.forward (fused HIP kernels), not stand-alone")
-
-
-class DoubleConv(_NoStandaloneForward):
+class DoubleConv(nn.Module):
     """(conv3x3 no-bias -> GroupNorm(8) -> LeakyReLU(0.2)) x 2   (reference unet_model.py:17-45)"""
 
     def __init__(self, in_channels, out_channels, mid_channels=None, dilation=1):
@@ -59,16 +55,22 @@ class DoubleConv(_NoStandaloneForward):
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
+    def forward(self, x):
+        return standalone.double_conv_forward(self, x)
 
-class Down(_NoStandaloneForward):
+
+class Down(nn.Module):
     """MaxPool2d(2) -> DoubleConv   (reference unet_model.py:47-57)"""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
 
+    def forward(self, x):
+        return standalone.down_forward(self, x)
 
-class Up(_NoStandaloneForward):
+
+class Up(nn.Module):
     """bilinear x2 -> conv1x1 -> GN -> LReLU -> pad -> cat[skip, up] -> DoubleConv (reference :59-94)"""
 
     def __init__(self, in_ch_up, in_ch_skip, out_channels):
@@ -81,8 +83,11 @@ class Up(_NoStandaloneForward):
         )
         self.conv = DoubleConv(in_ch_skip + (in_ch_up // 2), out_channels)
 
+    def forward(self, x1, x2):
+        return standalone.up_forward(self, x1, x2)
 
-class PixelShuffleUp(_NoStandaloneForward):
+
+class PixelShuffleUp(nn.Module):
     """conv3x3(bias) -> PixelShuffle -> GN -> LReLU   (reference unet_model.py:96-114)"""
 
     def __init__(self, in_channels, out_channels, scale_factor=2):
@@ -94,6 +99,9 @@ class PixelShuffleUp(_NoStandaloneForward):
         self.norm = nn.GroupNorm(num_groups=8, num_channels=out_channels)
         self.act = nn.LeakyReLU(negative_slope=0.2, inplace=True)
         icnr(self.conv.weight, scale_factor)
+
+    def forward(self, x):
+        return standalone.pixel_shuffle_up_forward(self, x)
 
 
 class _UNetFunction(torch.autograd.Function):
