@@ -57,6 +57,7 @@ extern "C" {
 #ifndef MRISR_STAT_SLOTS
 #define MRISR_STAT_SLOTS 16
 #endif
+#define MRISR_SP_HEAD 3 /* mrisr_consumer.spatial only: see there */
 #define MRISR_OUT_PLAIN 0
 #define MRISR_OUT_PIXEL_SHUFFLE2 1 /* out[n,2y+i,2x+j,c/4] = conv[n,y,x,c], c=4c'+2i+j (unet_model.py:102) */
 
@@ -171,6 +172,17 @@ typedef struct {
     int32_t spatial;      /* MRISR_SP_* that the consumer applied to this producer              */
     int32_t off_y, off_x; /* pad offsets (MRISR_SP_NONE consumers)                              */
     int32_t weight_mode;  /* 0: plain; 1: times sigmoid(alpha); 2: times 1-sigmoid(alpha)       */
+    /* MRISR_SP_HEAD only (NULL otherwise): the consumer is the output head nn.Conv2d(C, 1, 1) + sigmoid
+     * (unet_model.py:172, 211) and dL/dact is never materialised: da = dL/dout [N][H][W] fp32, head_out = the
+     * sigmoid output, head_w [C]:  dL/dact[n,y,x,c] = da*out*(1-out) * head_w[c].  The head's own gradients
+     * (mrisr_head_backward's job) come out of the same two passes: mrisr_act_bwd_reduce accumulates per-image
+     * partial sums into head_part [N][C+1] (zeroed scratch: sum dz*act per channel, then sum dz), and
+     * mrisr_act_bwd_apply_fused (with fin) adds them to head_dw [C] and head_db [1].                              */
+    const float* head_out;
+    const float* head_w;
+    float* head_part;
+    float* head_dw;
+    float* head_db;
 } mrisr_consumer;
 
 /* backward of LeakyReLU+GroupNorm for one producer tensor x [N][H][W][C] (raw conv output); restates
@@ -197,10 +209,25 @@ int mrisr_act_bwd_finalize(const float* red, const float* gamma, const float* me
 int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N,
                         int H, int W, int C, int out_mode, float* dbias, void* stream);
 /* apply without the intermediate tensor: when every consumer is MRISR_SP_NONE, mrisr_act_bwd_reduce may be called
- * with g = NULL and this entry gathers dL/dact from the consumers again (same arguments as the reduce pass).    */
+ * with g = NULL and this entry gathers dL/dact from the consumers again (same arguments as the reduce pass).
+ * Exactly one of coef / fin: with fin the finalize step runs inside this launch (the coefficients are derived from
+ * red by every workgroup, dgamma / dbeta / dalpha are accumulated once) and mrisr_act_bwd_finalize is not called.   */
+typedef struct mrisr_gn_bwd_fin {
+    const float* red;          /* [N][C][2] of the finished reduce pass                                   */
+    const float* gamma;        /* [C]                                                                     */
+    const float* meanrstd;     /* [N][groups][2]                                                          */
+    float* dgamma;             /* [C] accumulated                                                         */
+    float* dbeta;              /* [C] accumulated                                                         */
+    const float* alpha_slots;  /* optional, as for mrisr_act_bwd_finalize                                 */
+    const float* alpha;
+    float* dalpha;
+    double count;              /* (C/groups)*H*W                                                          */
+    float alpha_sign;
+    int32_t groups;            /* <= 32                                                                   */
+} mrisr_gn_bwd_fin;
 int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift, int nconsumers,
                               const mrisr_consumer* consumers, const float* blend_alpha, const float* coef,
-                              void* dx, int N, int H, int W, int C, void* stream);
+                              const mrisr_gn_bwd_fin* fin, void* dx, int N, int H, int W, int C, void* stream);
 /* out[C] += sum over pixels of x[npix][C]  (bias gradient of nn.Conv2d(bias=True), unet_model.py:101) */
 int mrisr_channel_sum(int dtype, const void* x, float* out, size_t npix, int C, void* stream);
 /* dalpha += sigmoid'(alpha) * sum da * (act0 - act1)   (unet_model.py:206-207)               */

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("MRISR_LIB") or os.path.join(_HERE, "libmrisr.so")   #
 
 F32, BF16, F16 = 0, 1, 2
 SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
-SP_NONE, SP_POOL2, SP_UP2 = 0, 1, 2
+SP_NONE, SP_POOL2, SP_UP2, SP_HEAD = 0, 1, 2, 3
 COMBINE_CONCAT, COMBINE_BLEND = 0, 1
 OUT_PLAIN, OUT_PIXEL_SHUFFLE2 = 0, 1
 STAT_SLOTS = 16      # = MRISR_STAT_SLOTS of include/mrisr.h; load() replaces it with the library's compiled value
@@ -47,10 +47,17 @@ class AugPhoto(C.Structure):
     _fields_ = [("contrast", C.c_float), ("mean", C.c_int32), ("noise_sigma", C.c_float), ("seed", C.c_uint32)]
 
 
+class GnBwdFin(C.Structure):
+    _fields_ = [("red", _fp), ("gamma", _fp), ("meanrstd", _fp), ("dgamma", _fp), ("dbeta", _fp),
+                ("alpha_slots", _fp), ("alpha", _fp), ("dalpha", _fp), ("count", C.c_double),
+                ("alpha_sign", C.c_float), ("groups", C.c_int32)]
+
+
 class Consumer(C.Structure):
     _fields_ = [("da", _vp), ("C_total", C.c_int32), ("c_off", C.c_int32), ("H", C.c_int32),
                 ("W", C.c_int32), ("spatial", C.c_int32), ("off_y", C.c_int32), ("off_x", C.c_int32),
-                ("weight_mode", C.c_int32)]
+                ("weight_mode", C.c_int32), ("head_out", _fp), ("head_w", _fp), ("head_part", _fp),
+                ("head_dw", _fp), ("head_db", _fp)]
 
 
 # every symbol include/mrisr.h declares: name -> (restype, argtypes)
@@ -76,7 +83,8 @@ SIGNATURES = {
     "mrisr_act_bwd_reduce": (_i, [_i, _vp, _fp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_act_bwd_finalize": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _fp, _fp, _fp, _f, _vp]),
     "mrisr_act_bwd_apply": (_i, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _fp, _vp]),
-    "mrisr_act_bwd_apply_fused": (_i, [_i, _vp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    "mrisr_act_bwd_apply_fused": (_i, [_i, _vp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _fp, C.POINTER(GnBwdFin), _vp, _i, _i,
+                                       _i, _i, _vp]),
     "mrisr_channel_sum": (_i, [_i, _vp, _fp, _sz, _i, _vp]),
     "mrisr_blend_alpha_grad": (_i, [_i, _vp, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mrisr_head_forward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -53,6 +53,11 @@ extern "C" int mrisr_gn_finalize(const double* stats, const float* gamma, const 
 struct ConsumerDev {
     const void* da;
     int C_total, c_off, H, W, spatial, off_y, off_x, weight_mode;
+    const float* head_out;      // MRISR_SP_HEAD: sigmoid output, 1x1 weight, per-image partial sums [N][C+1], and the
+    const float* head_w;        // head's own gradient accumulators
+    float* head_part;
+    float* head_dw;
+    float* head_db;
 };
 struct ActBwdParams {
     const void* x;
@@ -67,6 +72,70 @@ struct ActBwdParams {
     int nvec_shift;  // log2(C / VEC) when that is a power of two, else -1
     float* alpha_slots;   // [256] partial sums of (first consumer's gradient) * activation, or NULL (blend alpha gradient)
 };
+
+// Pass-2 coefficients computed inside the apply kernels (mrisr_gn_bwd_fin): what act_bwd_finalize_kernel does for the
+// g-tensor path, without its launch in the middle of the gradient chain.
+struct FinDev {
+    const float* red;        // [N][C][2], complete (written by the pass-1 launch)
+    const float* gamma;
+    const float* meanrstd;
+    float* dgamma;
+    float* dbeta;
+    const float* alpha_slots;
+    const float* alpha;
+    float* dalpha;
+    float inv_count, alpha_sign;
+    int groups;
+    const float* head_part;   // MRISR_SP_HEAD consumer: per-image partial sums [N][C+1] -> head_dw [C], head_db [1]
+    float* head_dw;
+    float* head_db;
+};
+constexpr int kMaxGroups = 32;
+
+// Every thread of the block calls this (two barriers inside).  s12 = 2 * kMaxGroups floats of LDS.  Fills the
+// coefficients of channels c .. c+VEC-1 of image n (see act_bwd_finalize_kernel for the formulas); the block with
+// `owner` set adds image n's share to dgamma / dbeta for the channels its threads with `lead` set hold, and the block
+// with `first` set turns the blend-alpha slots into dalpha.
+template <int VEC>
+__device__ __forceinline__ void gn_bwd_coefs(const FinDev& f, float* s12, int n, int C, int c, bool valid, bool owner,
+                                             bool lead, bool first, float* ca, float* cb, float* cc) {
+    const int t = threadIdx.x, gs = C / f.groups;
+    if (t < 2 * kMaxGroups) s12[t] = 0.f;
+    __syncthreads();
+    const float* rn = f.red + (size_t)n * C * 2;
+    for (int j = t; j < C; j += blockDim.x) {
+        const float gm = f.gamma[j];
+        atomicAdd(&s12[j / gs], gm * rn[2 * j]);
+        atomicAdd(&s12[kMaxGroups + j / gs], gm * rn[2 * j + 1]);
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int g = (c + e) / gs;
+            const float mean = f.meanrstd[((size_t)n * f.groups + g) * 2], rstd = f.meanrstd[((size_t)n * f.groups + g) * 2 + 1];
+            const float S1 = s12[g] * f.inv_count, S2 = s12[kMaxGroups + g] * f.inv_count;
+            ca[e] = rstd * f.gamma[c + e];
+            cb[e] = -rstd * rstd * S2;
+            cc[e] = mean * rstd * rstd * S2 - rstd * S1;
+            if (owner && lead) {
+                atomic_add_f32(&f.dbeta[c + e], rn[2 * (c + e)]);
+                atomic_add_f32(&f.dgamma[c + e], rn[2 * (c + e) + 1]);
+                if (f.head_part) atomic_add_f32(&f.head_dw[c + e], f.head_part[(size_t)n * (C + 1) + c + e]);
+            }
+        }
+        if (owner && lead && f.head_part && c == 0) atomic_add_f32(f.head_db, f.head_part[(size_t)n * (C + 1) + C]);
+    }
+    if (first && f.alpha_slots && t < 64) {      // dalpha += sign * sigmoid'(alpha) * sum d*act  (unet_model.py:206-207)
+        float v = 0.f;
+        for (int i = t; i < 256; i += 64) v += f.alpha_slots[i];
+        v = wave_sum(v);
+        if (t == 0) {
+            const float sg = 1.f / (1.f + __expf(-f.alpha[0]));
+            atomic_add_f32(f.dalpha, f.alpha_sign * sg * (1.f - sg) * v);
+        }
+    }
+}
 
 template <typename T>
 __device__ __forceinline__ void act_of(const T* p, const float* sc, const float* sh, float* o) {
@@ -98,9 +167,12 @@ __device__ __forceinline__ void up2_adjoint_weights(int y, int in_size, int* idx
 // PLAIN: every consumer is MRISR_SP_NONE (17 of the 20 nodes of the U-Net) - compiled without the pool / bilinear
 // adjoint code, whose 32-float windows cost the generic kernel 155 VGPRs = 3 waves per SIMD, too few loads in
 // flight for an HBM-bound pass (measured 3.0 TB/s).
-template <typename T, int KIND>   // 0: plain consumers only, 1: plain + 2x2 max-pool, 2: + bilinear adjoint gather
+// KIND 3: the single consumer is the output head (MRISR_SP_HEAD): dL/dact = dz * w[c] is formed on the fly from the
+// one-channel dz = dL/dout * out * (1 - out), and the head's dW / db fall out of the same pass.
+template <typename T, int KIND>   // 0: plain consumers only, 1: plain + 2x2 max-pool, 2: + bilinear adjoint gather, 3: head
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams p) {
-    constexpr bool PLAIN = KIND == 0;
+    constexpr bool PLAIN = KIND == 0 || KIND == 3;
+    constexpr bool HEAD = KIND == 3;
     constexpr int VEC = Vec16<T>::N;
     __shared__ float lds[256 * VEC * 2];
     const int t = threadIdx.x, n = blockIdx.y;
@@ -131,6 +203,11 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
     T* gb = (T*)p.g + (size_t)n * HW * p.C;
     const int pix_end = min(HW, (int)(blockIdx.x + 1) * p.pix_per_block);
     float adot = 0.f;
+    float hw[HEAD ? VEC : 1], hdw[HEAD ? VEC : 1], hdb = 0.f;
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { hw[e] = p.cons[0].head_w[c + e]; hdw[e] = 0.f; }
+    }
     if (active) {
         for (int pix = blockIdx.x * p.pix_per_block + pl; pix < pix_end; pix += ppb) {
             const int y = pix / p.W, x = pix - y * p.W;
@@ -138,7 +215,18 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
             float gact[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) gact[e] = 0.f;
-            for (int k = 0; k < p.ncons; ++k) {
+            if constexpr (HEAD) {
+                const size_t gp = (size_t)n * HW + pix;
+                const float o = p.cons[0].head_out[gp];
+                const float dz = ((const float*)p.cons[0].da)[gp] * o * (1.f - o);
+                if (cv == 0 && blockIdx.z == 0) hdb += dz;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    gact[e] = dz * hw[e];
+                    hdw[e] += dz * lrelu(xv.get(e) * sc[e] + sh[e]);
+                }
+            }
+            for (int k = 0; k < (HEAD ? 0 : p.ncons); ++k) {
                 const ConsumerDev& cs = p.cons[k];
                 const T* dab = (const T*)cs.da + (size_t)n * cs.H * cs.W * cs.C_total + cs.c_off + c;
                 const float wgt = cs.weight_mode == 0 ? 1.f : (cs.weight_mode == 1 ? bw[1] : bw[2]);
@@ -238,6 +326,22 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
         for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
         atomic_add_f32(&p.red[((size_t)n * p.C + cz + cvj * VEC + e) * 2 + which], s);
     }
+    if constexpr (HEAD) {     // the head's weight / bias gradient (what head_bwd_kernel accumulates), per image: all the
+        __syncthreads();      // blocks of the launch adding into ONE row of C floats serialise at the memory side
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) lds[t * VEC + e] = active ? hdw[e] : 0.f;
+        const float b = wave_sum(active ? hdb : 0.f);
+        if ((t & 63) == 0) lds[256 * VEC + (t >> 6)] = b;
+        __syncthreads();
+        float* part = p.cons[0].head_part + (size_t)n * (p.C + 1);
+        for (int j = t; j < nvec * VEC; j += 256) {
+            const int cvj = j / VEC, e = j - cvj * VEC;
+            float s = 0.f;
+            for (int q = 0; q < ppb; ++q) s += lds[(q * nvec + cvj) * VEC + e];
+            atomic_add_f32(&part[cz + cvj * VEC + e], s);
+        }
+        if (t == 0 && blockIdx.z == 0) atomic_add_f32(&part[p.C], lds[256 * VEC] + lds[256 * VEC + 1] + lds[256 * VEC + 2] + lds[256 * VEC + 3]);
+    }
 }
 
 // Nodes whose activation is also max-pooled (the encoder skips x1..x3): thread = (pooled pixel, channel vector) owning
@@ -247,9 +351,9 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(const ActBwdParams 
 // second consumer - a plain one with the node's own geometry (host-checked: act_bwd_window_ok).
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void act_bwd_pool_window_kernel(const ActBwdParams p, const float* __restrict__ coef,
-                                                                  T* __restrict__ dx) {
+                                                                  T* __restrict__ dx, const FinDev fin) {
     constexpr int VEC = Vec16<T>::N;
-    __shared__ float lds[APPLY ? 2 : 256 * VEC * 2];
+    __shared__ float lds[APPLY ? 2 * kMaxGroups : 256 * VEC * 2];
     const int t = threadIdx.x, n = blockIdx.y;
     const int cz = blockIdx.z * 256 * VEC;        // channel slice, see act_bwd_reduce_kernel
     const int nvec = min(256, p.C / VEC - (int)blockIdx.z * 256), ppb = 256 / nvec;
@@ -267,8 +371,12 @@ __global__ __launch_bounds__(256) void act_bwd_pool_window_kernel(const ActBwdPa
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         sc[e] = p.scale[k0 + e]; sh[e] = p.shift[k0 + e];
-        if constexpr (APPLY) { u0[e] = coef[k0 + e]; u1[e] = coef[NC + k0 + e]; u2[e] = coef[2 * NC + k0 + e]; }
-        else { u0[e] = 0.f; u1[e] = 0.f; u2[e] = 0.f; }
+        if constexpr (APPLY) {
+            if (coef) { u0[e] = coef[k0 + e]; u1[e] = coef[NC + k0 + e]; u2[e] = coef[2 * NC + k0 + e]; }
+        } else { u0[e] = 0.f; u1[e] = 0.f; u2[e] = 0.f; }
+    }
+    if constexpr (APPLY) {
+        if (!coef) gn_bwd_coefs<VEC>(fin, lds, n, p.C, c, active, blockIdx.x == 0, pl == 0, blockIdx.x + blockIdx.y + blockIdx.z == 0, u0, u1, u2);
     }
     const T* xb = (const T*)p.x + (size_t)n * p.H * W * p.C + c;
     const T* dpb = (const T*)p.cons[kp].da + (size_t)n * HWp * p.cons[kp].C_total + p.cons[kp].c_off + c;
@@ -352,8 +460,20 @@ static bool act_bwd_window_ok(int nconsumers, const mrisr_consumer* cs, int H, i
     return npool == 1;
 }
 
-template <typename T, bool SAME>
-__global__ void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef, T* __restrict__ dx);
+template <typename T, bool SAME, bool HEAD = false>
+__global__ void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef, T* __restrict__ dx, const FinDev fin);
+
+// MRISR_SP_HEAD: the only consumer, same geometry as the node, no blend weight
+static int check_head_consumer(int nconsumers, const mrisr_consumer* cs, int H, int W, int C, bool reduce, const char* who) {
+    bool head = false;
+    for (int k = 0; k < nconsumers; ++k) head = head || cs[k].spatial == MRISR_SP_HEAD;
+    if (!head) return MRISR_OK;
+    const mrisr_consumer& c = cs[0];
+    if (nconsumers != 1 || c.H != H || c.W != W || c.off_y || c.off_x || c.weight_mode || c.c_off || c.C_total != C)
+        MRISR_FAIL(MRISR_E_ARG, "%s: a head consumer is the only consumer and has the node's geometry", who);
+    if (!c.head_out || !c.head_w || !c.head_part || (!reduce && (!c.head_dw || !c.head_db))) MRISR_FAIL(MRISR_E_ARG, "%s: head consumer null pointer", who);
+    return MRISR_OK;
+}
 
 static int fill_act_bwd_params(ActBwdParams& p, int dtype, int nconsumers, const mrisr_consumer* consumers,
                                const float* blend_alpha, int H, int W, int C, const char* who) {
@@ -365,20 +485,38 @@ static int fill_act_bwd_params(ActBwdParams& p, int dtype, int nconsumers, const
         if (c.c_off % vec || c.C_total % vec || c.c_off + C > c.C_total) MRISR_FAIL(MRISR_E_SHAPE, "%s: consumer %d channels", who, k);
         if (c.spatial == MRISR_SP_UP2 && (c.off_y + 2 * H > c.H || c.off_x + 2 * W > c.W)) MRISR_FAIL(MRISR_E_SHAPE, "%s: consumer %d UP2 extent", who, k);
         if (c.spatial == MRISR_SP_POOL2 && (c.H != H / 2 || c.W != W / 2)) MRISR_FAIL(MRISR_E_SHAPE, "%s: consumer %d POOL2 extent", who, k);
-        p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode};
+        p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode, c.head_out, c.head_w, c.head_part, c.head_dw, c.head_db};
     }
     return MRISR_OK;
 }
 
 extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift,
                                          int nconsumers, const mrisr_consumer* consumers, const float* blend_alpha,
-                                         const float* coef, void* dx, int N, int H, int W, int C, void* stream) {
-    if (!x || !scale || !shift || !coef || !dx || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: null pointer");
+                                         const float* coef, const mrisr_gn_bwd_fin* fin, void* dx, int N, int H, int W,
+                                         int C, void* stream) {
+    if (!x || !scale || !shift || !dx || !consumers) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: null pointer");
+    if ((coef != nullptr) == (fin != nullptr)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: exactly one of coef / fin");
+    FinDev fd;
+    memset(&fd, 0, sizeof(fd));
+    if (fin) {
+        if (!fin->red || !fin->gamma || !fin->meanrstd || !fin->dgamma || !fin->dbeta) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: fin null pointer");
+        if (fin->groups <= 0 || fin->groups > kMaxGroups || C % fin->groups || !(fin->count > 0)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: fin groups %d", fin->groups);
+        if (fin->alpha_slots && (!fin->alpha || !fin->dalpha)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: alpha_slots without alpha/dalpha");
+        fd = FinDev{fin->red, fin->gamma, fin->meanrstd, fin->dgamma, fin->dbeta, fin->alpha_slots, fin->alpha, fin->dalpha,
+                    (float)(1.0 / fin->count), fin->alpha_sign, fin->groups, nullptr, nullptr, nullptr};
+    }
     if (nconsumers < 1 || nconsumers > 2) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: %d consumers", nconsumers);
     const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused: C %d", C);
+    int hrc = check_head_consumer(nconsumers, consumers, H, W, C, false, "act_bwd_apply_fused");
+    if (hrc) return hrc;
+    const bool head = consumers[0].spatial == MRISR_SP_HEAD;
+    if (head) {
+        if (!fin) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused: a head consumer needs fin (its dW / db are added up in this launch)");
+        fd.head_part = consumers[0].head_part; fd.head_dw = consumers[0].head_dw; fd.head_db = consumers[0].head_db;
+    }
     bool plain = true;
-    for (int k = 0; k < nconsumers; ++k) plain = plain && consumers[k].spatial == MRISR_SP_NONE;
+    for (int k = 0; k < nconsumers; ++k) plain = plain && (consumers[k].spatial == MRISR_SP_NONE || head);
     const bool window = !plain && act_bwd_window_ok(nconsumers, consumers, H, W);
     if (!plain && !window) MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply_fused: plain consumers (or one 2x2-pool consumer on an even-sized node) only");
     ActBwdParams p;
@@ -396,9 +534,9 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
         if (ppw > HWp) ppw = ceil_div(HWp, ppbw) * ppbw;
         p.pix_per_block = ppw;
         dim3 gridw(ceil_div(HWp, ppw), N, nslice);
-        if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, true><<<gridw, 256, 0, s>>>(p, coef, (bf16_t*)dx);
-        else if (dtype == MRISR_F16) act_bwd_pool_window_kernel<f16_t, true><<<gridw, 256, 0, s>>>(p, coef, (f16_t*)dx);
-        else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, true><<<gridw, 256, 0, s>>>(p, coef, (float*)dx);
+        if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, true><<<gridw, 256, 0, s>>>(p, coef, (bf16_t*)dx, fd);
+        else if (dtype == MRISR_F16) act_bwd_pool_window_kernel<f16_t, true><<<gridw, 256, 0, s>>>(p, coef, (f16_t*)dx, fd);
+        else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, true><<<gridw, 256, 0, s>>>(p, coef, (float*)dx, fd);
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
         MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
         return MRISR_OK;
@@ -412,14 +550,17 @@ extern "C" int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* 
     p.pix_per_block = ppblk;
     dim3 grid(ceil_div(HW, ppblk), N, nslice);
     if (dtype == MRISR_BF16) {
-        if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
-        else act_bwd_apply_fused_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx);
+        if (head) act_bwd_apply_fused_kernel<bf16_t, true, true><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx, fd);
+        else if (same) act_bwd_apply_fused_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx, fd);
+        else act_bwd_apply_fused_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p, coef, (bf16_t*)dx, fd);
     } else if (dtype == MRISR_F16) {
-        if (same) act_bwd_apply_fused_kernel<f16_t, true><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx);
-        else act_bwd_apply_fused_kernel<f16_t, false><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx);
+        if (head) act_bwd_apply_fused_kernel<f16_t, true, true><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx, fd);
+        else if (same) act_bwd_apply_fused_kernel<f16_t, true><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx, fd);
+        else act_bwd_apply_fused_kernel<f16_t, false><<<grid, 256, 0, s>>>(p, coef, (f16_t*)dx, fd);
     } else if (dtype == MRISR_F32) {
-        if (same) act_bwd_apply_fused_kernel<float, true><<<grid, 256, 0, s>>>(p, coef, (float*)dx);
-        else act_bwd_apply_fused_kernel<float, false><<<grid, 256, 0, s>>>(p, coef, (float*)dx);
+        if (head) act_bwd_apply_fused_kernel<float, true, true><<<grid, 256, 0, s>>>(p, coef, (float*)dx, fd);
+        else if (same) act_bwd_apply_fused_kernel<float, true><<<grid, 256, 0, s>>>(p, coef, (float*)dx, fd);
+        else act_bwd_apply_fused_kernel<float, false><<<grid, 256, 0, s>>>(p, coef, (float*)dx, fd);
     } else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("act_bwd_apply_fused");
     return MRISR_OK;
@@ -438,6 +579,10 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     p.x = x; p.scale = scale; p.shift = shift; p.meanrstd = meanrstd; p.blend_alpha = blend_alpha; p.g = g; p.red = red;
     p.alpha_slots = alpha_slots;
     if (alpha_slots && (consumers[0].spatial != MRISR_SP_NONE || !blend_alpha)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: alpha_slots needs a plain first consumer and blend_alpha");
+    int hrc = check_head_consumer(nconsumers, consumers, H, W, C, true, "act_bwd_reduce");
+    if (hrc) return hrc;
+    const bool head = consumers[0].spatial == MRISR_SP_HEAD;
+    if (head && g) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: a head consumer goes with g = NULL (mrisr_act_bwd_apply_fused)");
     p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C; p.groups = groups;
     for (int k = 0; k < nconsumers; ++k) {
         const mrisr_consumer& c = consumers[k];
@@ -446,7 +591,7 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
         if (c.c_off % vec || c.C_total % vec || c.c_off + C > c.C_total) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d channels", k);
         if (c.spatial == MRISR_SP_UP2 && (c.off_y + 2 * H > c.H || c.off_x + 2 * W > c.W)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d UP2 extent", k);
         if (c.spatial == MRISR_SP_POOL2 && (c.H != H / 2 || c.W != W / 2)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_reduce: consumer %d POOL2 extent", k);
-        p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode};
+        p.cons[k] = ConsumerDev{c.da, c.C_total, c.c_off, c.H, c.W, c.spatial, c.off_y, c.off_x, c.weight_mode, c.head_out, c.head_w, c.head_part, c.head_dw, c.head_db};
     }
     const int nslice = ceil_div(C / vec, 256);     // channel slices of 256 vectors (blockIdx.z)
     const int nvec = nslice > 1 ? 256 : C / vec, ppb = 256 / nvec;
@@ -462,18 +607,18 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
         p.pix_per_block = ppw;
         dim3 gridw(ceil_div(HWp, ppw), N, nslice);
         hipStream_t sw = (hipStream_t)stream;
-        if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (bf16_t*)nullptr);
-        else if (dtype == MRISR_F16) act_bwd_pool_window_kernel<f16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (f16_t*)nullptr);
-        else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, false><<<gridw, 256, 0, sw>>>(p, nullptr, (float*)nullptr);
+        if (dtype == MRISR_BF16) act_bwd_pool_window_kernel<bf16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (bf16_t*)nullptr, FinDev{});
+        else if (dtype == MRISR_F16) act_bwd_pool_window_kernel<f16_t, false><<<gridw, 256, 0, sw>>>(p, nullptr, (f16_t*)nullptr, FinDev{});
+        else if (dtype == MRISR_F32) act_bwd_pool_window_kernel<float, false><<<gridw, 256, 0, sw>>>(p, nullptr, (float*)nullptr, FinDev{});
         else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
         MRISR_CHECK_LAUNCH("act_bwd_reduce");
         return MRISR_OK;
     }
-    if (!g) {
+    if (!g && !head) {
         for (int k = 0; k < nconsumers; ++k)
             if (consumers[k].spatial != MRISR_SP_NONE) MRISR_FAIL(MRISR_E_ARG, "act_bwd_reduce: g = NULL needs plain consumers or a window-eligible pooled node");
     }
-    int kind = 0;
+    int kind = head ? 3 : 0;
     for (int k = 0; k < nconsumers; ++k) {
         if (consumers[k].spatial == MRISR_SP_POOL2 && kind < 1) kind = 1;
         if (consumers[k].spatial == MRISR_SP_UP2) kind = 2;
@@ -482,14 +627,17 @@ extern "C" int mrisr_act_bwd_reduce(int dtype, const void* x, const float* scale
     if (dtype == MRISR_BF16) {
         if (kind == 0) act_bwd_reduce_kernel<bf16_t, 0><<<grid, 256, 0, s>>>(p);
         else if (kind == 1) act_bwd_reduce_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p);
+        else if (kind == 3) act_bwd_reduce_kernel<bf16_t, 3><<<grid, 256, 0, s>>>(p);
         else act_bwd_reduce_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p);
     } else if (dtype == MRISR_F16) {
         if (kind == 0) act_bwd_reduce_kernel<f16_t, 0><<<grid, 256, 0, s>>>(p);
         else if (kind == 1) act_bwd_reduce_kernel<f16_t, 1><<<grid, 256, 0, s>>>(p);
+        else if (kind == 3) act_bwd_reduce_kernel<f16_t, 3><<<grid, 256, 0, s>>>(p);
         else act_bwd_reduce_kernel<f16_t, 2><<<grid, 256, 0, s>>>(p);
     } else if (dtype == MRISR_F32) {
         if (kind == 0) act_bwd_reduce_kernel<float, 0><<<grid, 256, 0, s>>>(p);
         else if (kind == 1) act_bwd_reduce_kernel<float, 1><<<grid, 256, 0, s>>>(p);
+        else if (kind == 3) act_bwd_reduce_kernel<float, 3><<<grid, 256, 0, s>>>(p);
         else act_bwd_reduce_kernel<float, 2><<<grid, 256, 0, s>>>(p);
     } else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_reduce: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("act_bwd_reduce");
@@ -598,13 +746,16 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const T* __restrict_
 // Block = (pixel range, image), thread = (pixel lane, 16-byte channel vector): the five per-(n,c) coefficient vectors
 // are loaded ONCE per thread.  Re-loading them per element put 160 B of L1 traffic next to every 48 B of HBM traffic
 // and capped the pass at ~3.7 TB/s.
-template <typename T, bool SAME>
+template <typename T, bool SAME, bool HEAD>     // HEAD: the single consumer is the output head (MRISR_SP_HEAD)
 __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdParams p, const float* __restrict__ coef,
-                                                                  T* __restrict__ dx) {
+                                                                  T* __restrict__ dx, const FinDev fin) {
     constexpr int VEC = Vec16<T>::N;
+    __shared__ float s12[2 * kMaxGroups];
     const int t = threadIdx.x, n = blockIdx.y;
     const int nvec = min(256, p.C / VEC - (int)blockIdx.z * 256), ppb = 256 / nvec;     // blockIdx.z: channel slice
     const int cv = t % nvec, pl = t / nvec, c = blockIdx.z * 256 * VEC + cv * VEC;
+    float sc[VEC], sh[VEC], ca[VEC], cb[VEC], cc[VEC];
+    if (!coef) gn_bwd_coefs<VEC>(fin, s12, n, p.C, c, pl < ppb, blockIdx.x == 0, pl == 0, blockIdx.x + blockIdx.y + blockIdx.z == 0, ca, cb, cc);
     if (pl >= ppb) return;
     const size_t NC = (size_t)p.N * p.C;
     const int HW = p.H * p.W;
@@ -615,22 +766,32 @@ __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdPa
     }
     const int m0 = p.cons[0].weight_mode, m1 = p.cons[1].weight_mode;
     const float w0 = m0 == 0 ? 1.f : (m0 == 1 ? bw1 : bw2), w1 = m1 == 0 ? 1.f : (m1 == 1 ? bw1 : bw2);
-    float sc[VEC], sh[VEC], ca[VEC], cb[VEC], cc[VEC];
     const size_t k0 = (size_t)n * p.C + c;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         sc[e] = p.scale[k0 + e]; sh[e] = p.shift[k0 + e];
-        ca[e] = coef[k0 + e]; cb[e] = coef[NC + k0 + e]; cc[e] = coef[2 * NC + k0 + e];
+        if (coef) { ca[e] = coef[k0 + e]; cb[e] = coef[NC + k0 + e]; cc[e] = coef[2 * NC + k0 + e]; }
     }
     const T* xb = (const T*)p.x + (size_t)n * HW * p.C + c;
     T* ob = dx + (size_t)n * HW * p.C + c;
     const T* d0b = (const T*)p.cons[0].da + (size_t)n * p.cons[0].H * p.cons[0].W * p.cons[0].C_total + p.cons[0].c_off + c;
     const T* d1b = p.ncons > 1 ? (const T*)p.cons[1].da + (size_t)n * p.cons[1].H * p.cons[1].W * p.cons[1].C_total + p.cons[1].c_off + c : d0b;
+    float hw[HEAD ? VEC : 1];
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) hw[e] = p.cons[0].head_w[c + e];
+    }
     const int pend = min(HW, (int)(blockIdx.x + 1) * p.pix_per_block);
     for (int pix = blockIdx.x * p.pix_per_block + pl; pix < pend; pix += ppb) {
         const Vec16<T> xv = load_vec16(xb + (size_t)pix * p.C);
         float gact[VEC];
-        if constexpr (SAME) {
+        if constexpr (HEAD) {
+            const size_t gp = (size_t)n * HW + pix;
+            const float o = p.cons[0].head_out[gp];
+            const float dz = ((const float*)p.cons[0].da)[gp] * o * (1.f - o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gact[e] = dz * hw[e];
+        } else if constexpr (SAME) {
             const Vec16<T> d0 = load_vec16(d0b + (size_t)pix * p.cons[0].C_total);
             if (p.ncons > 1) {
                 const Vec16<T> d1 = load_vec16(d1b + (size_t)pix * p.cons[1].C_total);

@@ -45,6 +45,10 @@ _WGRAD_STREAM = os.environ.get("MRISR_WGRAD_STREAM", "1") == "1"
 # CUs given to the second stream's weight-gradient kernels; the backward chain's convolutions are sized for the rest
 # (0 = no split: every persistent kernel is sized for the whole chip and the two streams take turns; -1 = half)
 _WGRAD_CUS = int(os.environ.get("MRISR_WGRAD_CUS", "-1"))
+# tuning (A/B): GroupNorm-backward coefficients from a finalize launch of their own instead of inside the apply kernels
+_SEPARATE_FINALIZE = os.environ.get("MRISR_SEPARATE_FINALIZE", "0") == "1"
+# tuning: size every persistent convolution for this many CUs (two independent steps side by side on one GPU)
+_CU_LIMIT = int(os.environ.get("MRISR_CU_LIMIT", "0"))
 # (also tried: input gradient first on the whole chip, the weight gradient behind it on 128-224 CUs so that it overlaps the
 # next node's memory-bound GroupNorm-backward passes instead of the input gradient: 9.33-9.41 ms/step, no better than the
 # half / half split's 9.37-9.39 on the same box - the two kinds of kernel also compete for HBM and for the power budget)
@@ -247,6 +251,7 @@ class UNetEngine:
         d.dtype, d.N, d.H, d.W = dt, N, layer.H, layer.W
         d.Cin, d.Cout, d.ksize, d.nsrc = layer.cin, layer.cout, layer.ks, len(layer.srcs)
         d.combine, d.out_mode, d.groups, d.relu_out = layer.combine, layer.out_mode, GN_GROUPS, 0
+        d.cu_limit = _CU_LIMIT
         if layer.blend_src:                         # materialised blend: one plain source
             d.nsrc, d.combine = 1, L.COMBINE_CONCAT
             d.src[0].ptr = layer.aux.data_ptr()
@@ -406,7 +411,8 @@ class UNetEngine:
 
         # one zero-filled arena for the per-node (sum g, sum g*xhat) buffers instead of 20 small fills
         # (+256 floats per node: slots of the blend-alpha partial sums, used by the two head branches only)
-        red_sizes = [N * n.C * 2 + 256 for n in self.nodes.values()]
+        # (the head's input node: + N*(C+1) per-image partial sums of the head's own dW / db)
+        red_sizes = [N * n.C * 2 + 256 + (N * (n.C + 1) if n is self.head_in else 0) for n in self.nodes.values()]
         red_arena = torch.zeros(sum(red_sizes), dtype=torch.float32, device=dev)
         red_off = {}
         o = 0
@@ -418,15 +424,18 @@ class UNetEngine:
             """dL/dact (gathered from consumers) -> dL/d(raw conv output), plus GN affine grads."""
             cons = (L.Consumer * 2)()
             uses_alpha = False
-            for i, (da, ctot, coff, ch, cw, sp, oy, ox, wm) in enumerate(n.consumers):
+            for i, (da, ctot, coff, ch, cw, sp, oy, ox, wm, *head) in enumerate(n.consumers):
                 cons[i].da = da.data_ptr()
                 cons[i].C_total, cons[i].c_off, cons[i].H, cons[i].W = ctot, coff, ch, cw
                 cons[i].spatial, cons[i].off_y, cons[i].off_x, cons[i].weight_mode = sp, oy, ox, wm
+                if head:      # the output head: (sigmoid output, 1x1 weight, per-image scratch, weight / bias gradient)
+                    (cons[i].head_out, cons[i].head_w, cons[i].head_part, cons[i].head_dw,
+                     cons[i].head_db) = (t.data_ptr() for t in head)
                 uses_alpha |= wm != 0
             # plain consumers (no pool gather) and a plain output: pass 2 re-gathers dL/dact instead of going through
             # a materialised g tensor (one 2-byte write + read per element less)
             # (a 2x2-pooled node on even dims qualifies too: the window kernels own a whole pooling window per thread)
-            plain = all(c[5] == L.SP_NONE for c in n.consumers)
+            plain = all(c[5] in (L.SP_NONE, L.SP_HEAD) for c in n.consumers)
             window = (not plain and n.H % 2 == 0 and n.W % 2 == 0
                       and sum(c[5] == L.SP_POOL2 for c in n.consumers) == 1
                       and all(c[5] == L.SP_POOL2 or (c[5] == L.SP_NONE and (c[3], c[4], c[6], c[7]) == (n.H, n.W, 0, 0))
@@ -442,16 +451,26 @@ class UNetEngine:
             L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
                    n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(), L.ptr(slots),
                    N, n.H, n.W, n.C, GN_GROUPS, st)
-            coef = torch.empty(3 * N * n.C, dtype=torch.float32, device=dev)
             count = float((n.C // GN_GROUPS) * n.H * n.W)
+            dalpha_ptr = grads["alpha"].data_ptr() if slots is not None else None
+            if fused and not _SEPARATE_FINALIZE:
+                # the finalize step (group sums -> pass-2 coefficients, dgamma / dbeta / dalpha) runs inside the apply launch
+                fin = L.GnBwdFin(red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
+                                 grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), L.ptr(slots), alpha_ptr, dalpha_ptr,
+                                 count, 1.0 if wm0 == 1 else -1.0, GN_GROUPS)
+                dx = torch.empty_like(n.raw)
+                L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                       len(n.consumers), cons, alpha_ptr, None, C.byref(fin), dx.data_ptr(), N, n.H, n.W, n.C, st)
+                n.consumers = []
+                return dx
+            coef = torch.empty(3 * N * n.C, dtype=torch.float32, device=dev)
             L.call("mrisr_act_bwd_finalize", red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
                    grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), coef.data_ptr(), N, n.C, GN_GROUPS, count,
-                   L.ptr(slots), alpha_ptr, grads["alpha"].data_ptr() if slots is not None else None,
-                   1.0 if wm0 == 1 else -1.0, st)
+                   L.ptr(slots), alpha_ptr, dalpha_ptr, 1.0 if wm0 == 1 else -1.0, st)
             if fused:
                 dx = torch.empty_like(n.raw)
                 L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
-                       len(n.consumers), cons, alpha_ptr, coef.data_ptr(), dx.data_ptr(), N, n.H, n.W, n.C, st)
+                       len(n.consumers), cons, alpha_ptr, coef.data_ptr(), None, dx.data_ptr(), N, n.H, n.W, n.C, st)
                 n.consumers = []
                 return dx
             if n.shuffled:
@@ -466,15 +485,12 @@ class UNetEngine:
             return dx
 
         # head (unet_model.py:172, 211)
+        # dL/dact = dz * w is never materialised: the node's two GroupNorm-backward passes form it on the fly from the
+        # one-channel dz = dout * out * (1 - out), and the first pass accumulates the head's dW / db
         hn = self.head_in
-        da = torch.empty_like(hn.raw)
-        L.call("mrisr_head_backward", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
-               params["final_conv.3.weight"].data_ptr(), ctx["out"].data_ptr(), dout.data_ptr(), da.data_ptr(),
-               grads["final_conv.3.weight"].data_ptr(), grads["final_conv.3.bias"].data_ptr(),
-               N, hn.H, hn.W, hn.C, st)
-        hn.consumers.append((da, hn.C, 0, hn.H, hn.W, L.SP_NONE, 0, 0, 0))
-        if bucket_hook:
-            bucket_hook("final_conv.3")
+        ho = red_off[hn.name][0] + N * hn.C * 2 + 256
+        hn.consumers.append((dout, hn.C, 0, hn.H, hn.W, L.SP_HEAD, 0, 0, 0, ctx["out"], params["final_conv.3.weight"],
+                             red_arena[ho:ho + N * (hn.C + 1)], grads["final_conv.3.weight"], grads["final_conv.3.bias"]))
 
         # second stream for the weight gradients (not while kernels are being timed with events on the main stream)
         side = None
@@ -503,6 +519,8 @@ class UNetEngine:
             # pixel-shuffle conv with bias: its bias gradient (channel sums of dy) comes out of the un-shuffling pass
             fuse_bias = layer.bias and o.shuffled
             dy = node_backward(o, grads[layer.name + ".bias"] if fuse_bias else None)
+            if o is hn and bucket_hook:
+                bucket_hook("final_conv.3")       # the head's dW / db came out of that node's first pass
             if layer.post_up:       # adjoint of the bilinear x2 that follows the low-resolution 1x1 conv
                 dyl = torch.empty((N, layer.H, layer.W, layer.cout), dtype=dtype, device=dev)
                 L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st)
@@ -542,6 +560,7 @@ class UNetEngine:
             dd.wpacked = self._packed[(layer.name, dt, 1)].data_ptr()
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
+            dd.cu_limit = _CU_LIMIT
             if side is not None and side_cus > 0:
                 dd.cu_limit = max(8, L.num_cus() - side_cus)
             self._launch("dgrad", dd, lambda: L.call("mrisr_conv_forward", C.byref(dd), st))

@@ -335,9 +335,11 @@ def test_act_backward(dt, mode):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("mode", ["same", "same2", "pad", "pool", "pool+skip"])
-def test_act_backward_without_g_tensor(dt, mode):
+@pytest.mark.parametrize("in_kernel_finalize", [False, True])
+def test_act_backward_without_g_tensor(dt, mode, in_kernel_finalize):
     """Pass 1 with g = NULL + mrisr_act_bwd_apply_fused (plain consumers, with and without the node's own geometry)
-    and the 2x2-window kernels of max-pooled nodes (even H, W)."""
+    and the 2x2-window kernels of max-pooled nodes (even H, W); pass-2 coefficients from mrisr_act_bwd_finalize or
+    derived inside the apply launch (mrisr_gn_bwd_fin)."""
     n, c, h, w = 2, 32, 18, 26
     x = rnd(n, c, h, w, seed=90)
     gamma, beta = 1 + 0.2 * rnd(c, seed=91), 0.1 * rnd(c, seed=92)
@@ -375,16 +377,72 @@ def test_act_backward_without_g_tensor(dt, mode):
            None, None, red.data_ptr(), None, n, h, w, c, 8, U.stream())
     dgam, dbet, coef = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.empty(3 * n * c, device=U.DEV)
     gdev = gamma.to(U.DEV)
-    L.call("mrisr_act_bwd_finalize", red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
-           coef.data_ptr(), n, c, 8, float((c // 8) * h * w), None, None, None, 0.0, U.stream())
     dx = torch.full_like(xd, float("nan"))
-    L.call("mrisr_act_bwd_apply_fused", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), len(cons), carr, None,
-           coef.data_ptr(), dx.data_ptr(), n, h, w, c, U.stream())
+    if in_kernel_finalize:
+        fin = L.GnBwdFin(red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), None, None, None,
+                         float((c // 8) * h * w), 0.0, 8)
+        L.call("mrisr_act_bwd_apply_fused", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), len(cons), carr, None,
+               None, C.byref(fin), dx.data_ptr(), n, h, w, c, U.stream())
+    else:
+        L.call("mrisr_act_bwd_finalize", red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+               coef.data_ptr(), n, c, 8, float((c // 8) * h * w), None, None, None, 0.0, U.stream())
+        L.call("mrisr_act_bwd_apply_fused", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), len(cons), carr, None,
+               coef.data_ptr(), None, dx.data_ptr(), n, h, w, c, U.stream())
     torch.cuda.synchronize()
     tol = 3e-4 if dt == L.F32 else 2e-2
     assert U.relerr(U.nchw(dx), xr.grad) <= tol
     assert U.relerr(dgam.cpu(), gr.grad) <= tol
     assert U.relerr(dbet.cpu(), br.grad) <= tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 32, 18, 26), (1, 16, 33, 7)])
+def test_act_backward_head_consumer(dt, shape):
+    """MRISR_SP_HEAD: the output head (1x1 conv + sigmoid) as the node's consumer - dL/dact = dz * w is formed inside
+    the two GroupNorm-backward passes, and pass 1 accumulates the head's dW / db (reference unet_model.py:169-172, 211)."""
+    n, c, h, w = shape
+    x = rnd(n, c, h, w, seed=110)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=111), 0.1 * rnd(c, seed=112)
+    wt, b = rnd(c, seed=113, scale=0.3), torch.tensor([0.1])
+    scale, shift, mr = _gn_forward_state(x, gamma, beta, dt)
+    xr = U.rounded(x, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    wr, bb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    act = F.leaky_relu(F.group_norm(xr, 8, gr, br, 1e-5), 0.2)
+    out = torch.sigmoid((act * wr.view(1, c, 1, 1)).sum(1) + bb)
+    dout = rnd(n, h, w, seed=114)
+    out.backward(dout)
+    xd, outd, doutd, wd = U.nhwc(x, dt), out.detach().to(U.DEV).contiguous(), dout.to(U.DEV), wt.to(U.DEV)
+    dw, db, part = torch.zeros(c, device=U.DEV), torch.zeros(1, device=U.DEV), torch.zeros(n * (c + 1), device=U.DEV)
+    carr = (L.Consumer * 2)()
+    carr[0].da, carr[0].C_total, carr[0].c_off, carr[0].H, carr[0].W = doutd.data_ptr(), c, 0, h, w
+    carr[0].spatial, carr[0].weight_mode = L.SP_HEAD, 0
+    carr[0].head_out, carr[0].head_w, carr[0].head_part = outd.data_ptr(), wd.data_ptr(), part.data_ptr()
+    carr[0].head_dw, carr[0].head_db = dw.data_ptr(), db.data_ptr()
+    red = torch.zeros(n * c * 2, device=U.DEV)
+    L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), 1, carr,
+           None, None, red.data_ptr(), None, n, h, w, c, 8, U.stream())
+    dgam, dbet, gdev = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), gamma.to(U.DEV)
+    fin = L.GnBwdFin(red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), None, None, None,
+                     float((c // 8) * h * w), 0.0, 8)
+    dx = torch.full_like(xd, float("nan"))
+    L.call("mrisr_act_bwd_apply_fused", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), 1, carr, None, None,
+           C.byref(fin), dx.data_ptr(), n, h, w, c, U.stream())
+    torch.cuda.synchronize()
+    tol = 3e-4 if dt == L.F32 else 2e-2
+    assert U.relerr(U.nchw(dx), xr.grad) <= tol
+    assert U.relerr(dgam.cpu(), gr.grad) <= tol
+    assert U.relerr(dbet.cpu(), br.grad) <= tol
+    assert U.relerr(dw.cpu(), wr.grad) <= (1e-4 if dt == L.F32 else 5e-3)     # act from the stored (rounded) x and the
+    assert U.relerr(db.cpu(), bb.grad) <= 1e-4                                # device's fp32 scale / shift
+    # a second consumer next to the head, or the g-tensor path, is refused
+    carr[1].da, carr[1].C_total, carr[1].H, carr[1].W, carr[1].spatial = xd.data_ptr(), c, h, w, L.SP_NONE
+    with pytest.raises(RuntimeError, match="head consumer"):
+        L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), 2, carr,
+               None, None, red.data_ptr(), None, n, h, w, c, 8, U.stream())
+    with pytest.raises(RuntimeError, match="g = NULL"):
+        L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), 1, carr,
+               None, dx.data_ptr(), red.data_ptr(), None, n, h, w, c, 8, U.stream())
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -434,6 +492,24 @@ def test_blend_alpha_grad_and_channel_sum(dt):
                coef.data_ptr(), n, c, 8, float((c // 8) * h * w), red[n * c * 2:].data_ptr(), dev[7].data_ptr(),
                dal2.data_ptr(), sign, U.stream())
     assert abs(dal2.item() - alpha.grad.item()) <= 2e-4 * abs(alpha.grad.item()) + 1e-5
+    # ... and with the finalize step inside the apply launch
+    dal3 = torch.zeros(1, device=U.DEV)
+    for xi, si, ti, wm, sign in ((dev[1], dev[2], dev[3], 1, 1.0), (dev[4], dev[5], dev[6], 2, -1.0)):
+        carr = (L.Consumer * 2)()
+        carr[0].da, carr[0].C_total, carr[0].c_off, carr[0].H, carr[0].W = dev[0].data_ptr(), c, 0, h, w
+        carr[0].spatial, carr[0].weight_mode = L.SP_NONE, wm
+        red = torch.zeros(n * c * 2 + 256, device=U.DEV)
+        mr = torch.zeros(n * 8 * 2, device=U.DEV)
+        mr[1::2] = 1.0
+        L.call("mrisr_act_bwd_reduce", dt, xi.data_ptr(), si.data_ptr(), ti.data_ptr(), mr.data_ptr(), 1, carr,
+               dev[7].data_ptr(), None, red.data_ptr(), red[n * c * 2:].data_ptr(), n, h, w, c, 8, U.stream())
+        dg, db, gam = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV), torch.ones(c, device=U.DEV)
+        fin = L.GnBwdFin(red.data_ptr(), gam.data_ptr(), mr.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                         red[n * c * 2:].data_ptr(), dev[7].data_ptr(), dal3.data_ptr(), float((c // 8) * h * w), sign, 8)
+        dxo = torch.empty_like(xi)
+        L.call("mrisr_act_bwd_apply_fused", dt, xi.data_ptr(), si.data_ptr(), ti.data_ptr(), 1, carr, dev[7].data_ptr(),
+               None, C.byref(fin), dxo.data_ptr(), n, h, w, c, U.stream())
+    assert abs(dal3.item() - alpha.grad.item()) <= 2e-4 * abs(alpha.grad.item()) + 1e-5
     cs = torch.zeros(c, device=U.DEV)
     L.call("mrisr_channel_sum", dt, dev[0].data_ptr(), cs.data_ptr(), n * h * w, c, U.stream())
     assert U.relerr(cs.cpu(), U.rounded(da, dt).sum((0, 2, 3))) <= 1e-4

@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().mrisr_pack_weights(0, None, 8, 8, 3, 0, None, None) == -1
     assert b"null" in _lib.load().mrisr_last_error()
     # struct layouts match the header (sizes as compiled by the C side are fixed by the field lists)
-    assert ctypes.sizeof(_lib.Src) == 56 and ctypes.sizeof(_lib.Consumer) == 40 and ctypes.sizeof(_lib.PackJob) == 32
+    assert ctypes.sizeof(_lib.Src) == 56 and ctypes.sizeof(_lib.Consumer) == 80 and ctypes.sizeof(_lib.PackJob) == 32
+    assert ctypes.sizeof(_lib.GnBwdFin) == 80
 
 
 def test_module_contract_matches_reference_spec():

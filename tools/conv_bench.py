@@ -61,7 +61,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     tot = {}
     for name, cin, cout, ks, rel, sp, nsrc, comb in LAYERS:
-        if a.filter and a.filter not in name:
+        if a.filter and not any(f in name for f in a.filter.split(",")):
             continue
         cin, cout = int(cin * fs), int(cout * fs)
         H = W = int(S * rel)
