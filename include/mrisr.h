@@ -228,6 +228,13 @@ typedef struct mrisr_gn_bwd_fin {
 int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift, int nconsumers,
                               const mrisr_consumer* consumers, const float* blend_alpha, const float* coef,
                               const mrisr_gn_bwd_fin* fin, void* dx, int N, int H, int W, int C, void* stream);
+/* the same for a pixel-shuffled node (unet_model.py:102): one plain consumer with the node's geometry, even H and W; dx
+ * is stored un-shuffled as [N][H/2][W/2][4C] (channel 4c + 2(Y&1) + (X&1)) and dbias (optional, [4C] fp32 accumulated) +=
+ * the channel sums of dx = the producing conv's bias gradient (as mrisr_act_bwd_apply's PIXEL_SHUFFLE2 mode).       */
+int mrisr_act_bwd_apply_fused_unshuffle(int dtype, const void* x, const float* scale, const float* shift,
+                                        const mrisr_consumer* consumer, const float* blend_alpha,
+                                        const mrisr_gn_bwd_fin* fin, void* dx, float* dbias, int N, int H, int W, int C,
+                                        void* stream);
 /* out[C] += sum over pixels of x[npix][C]  (bias gradient of nn.Conv2d(bias=True), unet_model.py:101) */
 int mrisr_channel_sum(int dtype, const void* x, float* out, size_t npix, int C, void* stream);
 /* dalpha += sigmoid'(alpha) * sum da * (act0 - act1)   (unet_model.py:206-207)               */

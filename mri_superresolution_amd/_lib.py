@@ -85,6 +85,8 @@ SIGNATURES = {
     "mrisr_act_bwd_apply": (_i, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _fp, _vp]),
     "mrisr_act_bwd_apply_fused": (_i, [_i, _vp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _fp, C.POINTER(GnBwdFin), _vp, _i, _i,
                                        _i, _i, _vp]),
+    "mrisr_act_bwd_apply_fused_unshuffle": (_i, [_i, _vp, _fp, _fp, C.POINTER(Consumer), _fp, C.POINTER(GnBwdFin), _vp, _fp, _i,
+                                                 _i, _i, _i, _vp]),
     "mrisr_channel_sum": (_i, [_i, _vp, _fp, _sz, _i, _vp]),
     "mrisr_blend_alpha_grad": (_i, [_i, _vp, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mrisr_head_forward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

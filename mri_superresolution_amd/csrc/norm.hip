@@ -882,6 +882,119 @@ __global__ __launch_bounds__(256) void act_bwd_apply_unshuffle_kernel(const T* _
     }
 }
 
+// Pass 2 of a pixel-shuffled node without the intermediate g tensor: dx is stored un-shuffled, [N][H/2][W/2][4C] with
+// channel 4c + 2(Y&1) + (X&1) (the producing conv's own output layout).  Thread = (2x2 window of the shuffled image,
+// 16-byte channel vector): eight full-vector loads (x and the consumer's gradient at the four pixels) and 4*VEC
+// consecutive destination channels = one contiguous 4*16-byte store.  dbias (optional, [4C]) += channel sums of dx.
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_unshuffle_window_kernel(const ActBwdParams p, T* __restrict__ dx,
+                                                                       float* __restrict__ dbias, const FinDev fin) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float lds[256 * 4 * VEC];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int cz = blockIdx.z * 256 * VEC;
+    const int nvec = min(256, p.C / VEC - (int)blockIdx.z * 256), ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cz + cv * VEC;
+    const bool active = pl < ppb;
+    const int Hp = p.H / 2, Wp = p.W / 2, HWp = Hp * Wp, W = p.W;
+    float sc[VEC], sh[VEC], ca[VEC], cb[VEC], cc[VEC], bs[4 * VEC];
+    gn_bwd_coefs<VEC>(fin, lds, n, p.C, c, active, blockIdx.x == 0, pl == 0, blockIdx.x + blockIdx.y + blockIdx.z == 0, ca, cb, cc);
+    float w0 = 1.f;
+    if (p.blend_alpha) {
+        const float a = 1.f / (1.f + __expf(-p.blend_alpha[0]));
+        w0 = p.cons[0].weight_mode == 0 ? 1.f : (p.cons[0].weight_mode == 1 ? a : 1.f - a);
+    }
+    const size_t k0 = (size_t)n * p.C + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = active ? p.scale[k0 + e] : 0.f;
+        sh[e] = active ? p.shift[k0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * VEC; ++i) bs[i] = 0.f;
+    const T* xb = (const T*)p.x + (size_t)n * p.H * W * p.C + c;
+    const T* db = (const T*)p.cons[0].da + (size_t)n * p.H * W * p.cons[0].C_total + p.cons[0].c_off + c;
+    const int Ct = p.cons[0].C_total;
+    T* ob = dx + (size_t)n * HWp * 4 * p.C + 4 * c;
+    const int pend = min(HWp, (int)(blockIdx.x + 1) * p.pix_per_block);
+    if (active) {
+        for (int pp = blockIdx.x * p.pix_per_block + pl; pp < pend; pp += ppb) {
+            const int py = pp / Wp, px = pp - py * Wp;
+            const size_t b0 = (size_t)(2 * py) * W + 2 * px;
+            const size_t off[4] = {b0, b0 + 1, b0 + W, b0 + W + 1};
+            Vec16<T> xv[4], dv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xv[q] = load_vec16(xb + off[q] * p.C); dv[q] = load_vec16(db + off[q] * Ct); }
+            Vec16<T> ov[4];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xr = xv[q].get(e);
+                    const float pre = xr * sc[e] + sh[e];
+                    const float gy = w0 * dv[q].get(e) * (pre > 0.f ? 1.f : LRELU_SLOPE);
+                    const int i = 4 * e + q;          // destination channel 4(c + e) + q
+                    ov[i / VEC].set(i % VEC, gy * ca[e] + xr * cb[e] + cc[e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store_vec16(ob + (size_t)pp * 4 * p.C + j * VEC, ov[j]);
+            if (dbias) {
+#pragma unroll
+                for (int i = 0; i < 4 * VEC; ++i) bs[i] += ov[i / VEC].get(i % VEC);     // (the rounded value the weight-gradient kernel will read)
+            }
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4 * VEC; ++i) lds[t * 4 * VEC + i] = active ? bs[i] : 0.f;
+        __syncthreads();
+        for (int j = t; j < nvec * 4 * VEC; j += 256) {
+            const int cvj = j / (4 * VEC), i = j - cvj * 4 * VEC;
+            float v = 0.f;
+            for (int q = 0; q < ppb; ++q) v += lds[(q * nvec + cvj) * 4 * VEC + i];
+            atomic_add_f32(&dbias[4 * (cz + cvj * VEC) + i], v);
+        }
+    }
+}
+
+extern "C" int mrisr_act_bwd_apply_fused_unshuffle(int dtype, const void* x, const float* scale, const float* shift,
+                                                   const mrisr_consumer* consumer, const float* blend_alpha,
+                                                   const mrisr_gn_bwd_fin* fin, void* dx, float* dbias, int N, int H, int W,
+                                                   int C, void* stream) {
+    if (!x || !scale || !shift || !dx || !consumer || !fin) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused_unshuffle: null pointer");
+    if (!fin->red || !fin->gamma || !fin->meanrstd || !fin->dgamma || !fin->dbeta) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused_unshuffle: fin null pointer");
+    if (fin->groups <= 0 || fin->groups > kMaxGroups || C % fin->groups || !(fin->count > 0)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused_unshuffle: fin groups %d", fin->groups);
+    if (fin->alpha_slots && (!fin->alpha || !fin->dalpha)) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply_fused_unshuffle: alpha_slots without alpha/dalpha");
+    const int vec = mrisr_vec(dtype);
+    if (C % vec || ((H | W) & 1)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_apply_fused_unshuffle: C %d, H %d, W %d (even dims)", C, H, W);
+    if (consumer->spatial != MRISR_SP_NONE || consumer->H != H || consumer->W != W || consumer->off_y || consumer->off_x)
+        MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_apply_fused_unshuffle: one plain consumer with the node's geometry");
+    ActBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.scale = scale; p.shift = shift; p.blend_alpha = blend_alpha;
+    p.ncons = 1; p.N = N; p.H = H; p.W = W; p.C = C;
+    int rc = fill_act_bwd_params(p, dtype, 1, consumer, blend_alpha, H, W, C, "act_bwd_apply_fused_unshuffle");
+    if (rc) return rc;
+    const FinDev fd{fin->red, fin->gamma, fin->meanrstd, fin->dgamma, fin->dbeta, fin->alpha_slots, fin->alpha, fin->dalpha,
+                    (float)(1.0 / fin->count), fin->alpha_sign, fin->groups, nullptr, nullptr, nullptr};
+    const int nslice = ceil_div(C / vec, 256), nvs = nslice > 1 ? 256 : C / vec;
+    const int ppbw = 256 / nvs, HWp = (H / 2) * (W / 2);
+    // every block ends in 4C same-row float atomics when the bias gradient is asked for: few, long-running blocks
+    int ppw = ppbw * 16;
+    if (ppw > HWp) ppw = ceil_div(HWp, ppbw) * ppbw;
+    p.pix_per_block = ppw;
+    dim3 grid(ceil_div(HWp, ppw), N, nslice);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) act_bwd_unshuffle_window_kernel<bf16_t><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, dbias, fd);
+    else if (dtype == MRISR_F16) act_bwd_unshuffle_window_kernel<f16_t><<<grid, 256, 0, s>>>(p, (f16_t*)dx, dbias, fd);
+    else if (dtype == MRISR_F32) act_bwd_unshuffle_window_kernel<float><<<grid, 256, 0, s>>>(p, (float*)dx, dbias, fd);
+    else MRISR_FAIL(MRISR_E_DTYPE, "act_bwd_apply_fused_unshuffle: dtype %d", dtype);
+    MRISR_CHECK_LAUNCH("act_bwd_apply_fused_unshuffle");
+    return MRISR_OK;
+}
+
 extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, const float* coef, void* dx, int N, int H,
                                    int W, int C, int out_mode, float* dbias, void* stream) {
     if (!x || !g || !coef || !dx) MRISR_FAIL(MRISR_E_ARG, "act_bwd_apply: null pointer");

@@ -45,8 +45,6 @@ _WGRAD_STREAM = os.environ.get("MRISR_WGRAD_STREAM", "1") == "1"
 # CUs given to the second stream's weight-gradient kernels; the backward chain's convolutions are sized for the rest
 # (0 = no split: every persistent kernel is sized for the whole chip and the two streams take turns; -1 = half)
 _WGRAD_CUS = int(os.environ.get("MRISR_WGRAD_CUS", "-1"))
-# tuning (A/B): GroupNorm-backward coefficients from a finalize launch of their own instead of inside the apply kernels
-_SEPARATE_FINALIZE = os.environ.get("MRISR_SEPARATE_FINALIZE", "0") == "1"
 # tuning: size every persistent convolution for this many CUs (two independent steps side by side on one GPU)
 _CU_LIMIT = int(os.environ.get("MRISR_CU_LIMIT", "0"))
 # (also tried: input gradient first on the whole chip, the weight gradient behind it on 128-224 CUs so that it overlaps the
@@ -441,7 +439,11 @@ class UNetEngine:
                       and all(c[5] == L.SP_POOL2 or (c[5] == L.SP_NONE and (c[3], c[4], c[6], c[7]) == (n.H, n.W, 0, 0))
                               for c in n.consumers))
             fused = (not n.shuffled) and (plain or window)
-            g = None if fused else torch.empty_like(n.raw)
+            # pixel-shuffled node with one plain consumer of its own geometry: the same, stored un-shuffled
+            c0 = n.consumers[0]
+            fused_ps = (n.shuffled and len(n.consumers) == 1 and c0[5] == L.SP_NONE and n.H % 2 == 0 and n.W % 2 == 0
+                        and (c0[3], c0[4], c0[6], c0[7]) == (n.H, n.W, 0, 0))
+            g = None if (fused or fused_ps) else torch.empty_like(n.raw)
             alpha_ptr = params["alpha"].data_ptr() if uses_alpha else None
             red = red_arena[red_off[n.name][0]:red_off[n.name][0] + red_off[n.name][1]]
             # blend branches: dL/dalpha = sigmoid'(alpha) * sum dain * (act_bilinear - act_pixelshuffle) falls out of
@@ -453,11 +455,17 @@ class UNetEngine:
                    N, n.H, n.W, n.C, GN_GROUPS, st)
             count = float((n.C // GN_GROUPS) * n.H * n.W)
             dalpha_ptr = grads["alpha"].data_ptr() if slots is not None else None
-            if fused and not _SEPARATE_FINALIZE:
+            if fused or fused_ps:
                 # the finalize step (group sums -> pass-2 coefficients, dgamma / dbeta / dalpha) runs inside the apply launch
                 fin = L.GnBwdFin(red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
                                  grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), L.ptr(slots), alpha_ptr, dalpha_ptr,
                                  count, 1.0 if wm0 == 1 else -1.0, GN_GROUPS)
+                if fused_ps:
+                    dx = torch.empty((N, n.H // 2, n.W // 2, 4 * n.C), dtype=dtype, device=dev)
+                    L.call("mrisr_act_bwd_apply_fused_unshuffle", dt, n.raw.data_ptr(), n.scale.data_ptr(),
+                           n.shift.data_ptr(), cons, alpha_ptr, C.byref(fin), dx.data_ptr(), L.ptr(dbias), N, n.H, n.W, n.C, st)
+                    n.consumers = []
+                    return dx
                 dx = torch.empty_like(n.raw)
                 L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
                        len(n.consumers), cons, alpha_ptr, None, C.byref(fin), dx.data_ptr(), N, n.H, n.W, n.C, st)
@@ -467,12 +475,6 @@ class UNetEngine:
             L.call("mrisr_act_bwd_finalize", red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
                    grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), coef.data_ptr(), N, n.C, GN_GROUPS, count,
                    L.ptr(slots), alpha_ptr, dalpha_ptr, 1.0 if wm0 == 1 else -1.0, st)
-            if fused:
-                dx = torch.empty_like(n.raw)
-                L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
-                       len(n.consumers), cons, alpha_ptr, coef.data_ptr(), None, dx.data_ptr(), N, n.H, n.W, n.C, st)
-                n.consumers = []
-                return dx
             if n.shuffled:
                 dx = torch.empty((N, n.H // 2, n.W // 2, 4 * n.C), dtype=dtype, device=dev)
                 mode = L.OUT_PIXEL_SHUFFLE2

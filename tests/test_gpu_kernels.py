@@ -396,6 +396,47 @@ def test_act_backward_without_g_tensor(dt, mode, in_kernel_finalize):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,wm", [((2, 32, 18, 26), 0), ((1, 16, 6, 40), 2)])
+def test_act_backward_unshuffle_without_g_tensor(dt, shape, wm):
+    """Pixel-shuffled node, one plain consumer of its own geometry: pass 2 stores dx un-shuffled straight from the
+    consumer's gradient (mrisr_act_bwd_apply_fused_unshuffle), plus the producing conv's bias gradient."""
+    n, c, h, w = shape
+    x = rnd(n, c, h, w, seed=120)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=121), 0.1 * rnd(c, seed=122)
+    scale, shift, mr = _gn_forward_state(x, gamma, beta, dt)
+    alpha = torch.tensor([0.3])
+    wgt = 1.0 if wm == 0 else float(1 - torch.sigmoid(alpha))
+    xr = U.rounded(x, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    act = F.leaky_relu(F.group_norm(xr, 8, gr, br, 1e-5), 0.2)
+    da = rnd(n, c, h, w, seed=123)
+    (act * U.rounded(da, dt) * wgt).sum().backward()
+    xd, dad, ad, gdev = U.nhwc(x, dt), U.nhwc(da, dt), alpha.to(U.DEV), gamma.to(U.DEV)
+    carr = (L.Consumer * 2)()
+    carr[0].da, carr[0].C_total, carr[0].c_off, carr[0].H, carr[0].W = dad.data_ptr(), c, 0, h, w
+    carr[0].spatial, carr[0].weight_mode = L.SP_NONE, wm
+    red = torch.zeros(n * c * 2, device=U.DEV)
+    L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), 1, carr,
+           ad.data_ptr() if wm else None, None, red.data_ptr(), None, n, h, w, c, 8, U.stream())
+    dgam, dbet = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV)
+    fin = L.GnBwdFin(red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), None, None, None,
+                     float((c // 8) * h * w), 0.0, 8)
+    dx = torch.full((n, h // 2, w // 2, 4 * c), float("nan"), dtype=U.tdt(dt), device=U.DEV)
+    dbias = torch.zeros(4 * c, device=U.DEV)
+    L.call("mrisr_act_bwd_apply_fused_unshuffle", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), carr,
+           ad.data_ptr() if wm else None, C.byref(fin), dx.data_ptr(), dbias.data_ptr(), n, h, w, c, U.stream())
+    torch.cuda.synchronize()
+    tol = 3e-4 if dt == L.F32 else 2e-2
+    assert U.relerr(F.pixel_shuffle(U.nchw(dx), 2), xr.grad) <= tol
+    assert U.relerr(dbias.cpu(), U.nchw(dx).sum((0, 2, 3))) <= (1e-4 if dt == L.F32 else 2e-3)
+    assert U.relerr(dgam.cpu(), gr.grad) <= tol
+    assert U.relerr(dbet.cpu(), br.grad) <= tol
+    with pytest.raises(RuntimeError, match="even dims"):
+        L.call("mrisr_act_bwd_apply_fused_unshuffle", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), carr,
+               None, C.byref(fin), dx.data_ptr(), None, n, h + 1, w, c, U.stream())
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape", [(2, 32, 18, 26), (1, 16, 33, 7)])
 def test_act_backward_head_consumer(dt, shape):
     """MRISR_SP_HEAD: the output head (1x1 conv + sigmoid) as the node's consumer - dL/dact = dz * w is formed inside
