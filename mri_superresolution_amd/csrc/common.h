@@ -142,7 +142,10 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 
 // bilinear x2 align_corners=True source coordinate, as aten's area_pixel_compute_source_index:
 // scale = (in-1)/(out-1) in float, src = scale*dst.
+// (no fma contraction: aten rounds src to fp32 before taking the fraction; scale * dst - i0 as ONE fma moves the
+// weight by up to an ulp of src, 1.5e-5 at row 255)
 __device__ __forceinline__ void up2_coord(int dst, int in_size, int& i0, int& i1, float& w1) {
+#pragma clang fp contract(off)
     const int out_size = 2 * in_size;
     const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
     const float src = scale * (float)dst;

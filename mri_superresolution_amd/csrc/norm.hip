@@ -1034,27 +1034,34 @@ extern "C" int mrisr_act_bwd_apply(int dtype, const void* x, const void* g, cons
 // out = sigmoid(alpha) * act0 + (1 - sigmoid(alpha)) * act1, act_i = LeakyReLU(x_i*scale_i+shift_i)  (unet_model.py:206-207):
 // the blended input of final_conv.0, materialised.  With 32 channels the conv and its weight gradient are
 // staging-bound, and the two-source blending loader doubles that staging; one plain tensor halves it.
+// Block = (pixel range, image), thread = (pixel lane, 16-byte channel vector): the four per-(n,c) coefficient vectors are
+// loaded once per thread and all index arithmetic is 32-bit.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_blend_kernel(const T* __restrict__ x0, const float* __restrict__ sc0,
                                                          const float* __restrict__ sh0, const T* __restrict__ x1,
                                                          const float* __restrict__ sc1, const float* __restrict__ sh1,
-                                                         const float* __restrict__ alpha, T* __restrict__ out, int N,
-                                                         size_t HW, int C) {
+                                                         const float* __restrict__ alpha, T* __restrict__ out, int HW,
+                                                         int C, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    const int nvec = C / VEC;
-    const size_t total = (size_t)N * HW * nvec;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = C / VEC, ppb = 256 / nvec;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    if (pl >= ppb) return;
     const float a = 1.f / (1.f + __expf(-alpha[0])), b = 1.f - a;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int cv = idx % nvec;
-        const size_t pix = idx / nvec;
-        const int n = pix / HW;
-        const size_t k0 = (size_t)n * C + cv * VEC;
-        const Vec16<T> v0 = load_vec16(x0 + idx * VEC), v1 = load_vec16(x1 + idx * VEC);
+    float s0[VEC], t0[VEC], s1[VEC], t1[VEC];
+    const size_t k0 = (size_t)n * C + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s0[e] = sc0[k0 + e]; t0[e] = sh0[k0 + e]; s1[e] = sc1[k0 + e]; t1[e] = sh1[k0 + e]; }
+    const size_t base = (size_t)n * HW * C + c;
+    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
+    for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
+        const size_t o_ = base + (size_t)pix * C;
+        const Vec16<T> v0 = load_vec16(x0 + o_), v1 = load_vec16(x1 + o_);
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            o.set(e, a * lrelu(v0.get(e) * sc0[k0 + e] + sh0[k0 + e]) + b * lrelu(v1.get(e) * sc1[k0 + e] + sh1[k0 + e]));
-        store_vec16(out + idx * VEC, o);
+            o.set(e, a * lrelu(v0.get(e) * s0[e] + t0[e]) + b * lrelu(v1.get(e) * s1[e] + t1[e]));
+        store_vec16(out + o_, o);
     }
 }
 
@@ -1063,13 +1070,16 @@ extern "C" int mrisr_norm_blend(int dtype, const void* x0, const float* scale0, 
                                 int W, int C, void* stream) {
     if (!x0 || !scale0 || !shift0 || !x1 || !scale1 || !shift1 || !alpha || !out) MRISR_FAIL(MRISR_E_ARG, "norm_blend: null pointer");
     const int vec = mrisr_vec(dtype);
-    if (N <= 0 || H <= 0 || W <= 0 || C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_blend: N %d H %d W %d C %d", N, H, W, C);
-    const size_t total = (size_t)N * H * W * (C / vec);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (N <= 0 || N > 65535 || H <= 0 || W <= 0 || C % vec || C / vec > 256) MRISR_FAIL(MRISR_E_SHAPE, "norm_blend: N %d H %d W %d C %d", N, H, W, C);
+    if ((size_t)H * W >= (1u << 30)) MRISR_FAIL(MRISR_E_SHAPE, "norm_blend: image %dx%d", H, W);
+    const int nvec = C / vec, ppb = 256 / nvec, HW = H * W;
+    int ppblk = ppb * 32;
+    if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
+    dim3 grid(ceil_div(HW, ppblk), N);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MRISR_BF16) norm_blend_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x0, scale0, shift0, (const bf16_t*)x1, scale1, shift1, alpha, (bf16_t*)out, N, (size_t)H * W, C);
-    else if (dtype == MRISR_F16) norm_blend_kernel<f16_t><<<blocks, 256, 0, s>>>((const f16_t*)x0, scale0, shift0, (const f16_t*)x1, scale1, shift1, alpha, (f16_t*)out, N, (size_t)H * W, C);
-    else if (dtype == MRISR_F32) norm_blend_kernel<float><<<blocks, 256, 0, s>>>((const float*)x0, scale0, shift0, (const float*)x1, scale1, shift1, alpha, (float*)out, N, (size_t)H * W, C);
+    if (dtype == MRISR_BF16) norm_blend_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x0, scale0, shift0, (const bf16_t*)x1, scale1, shift1, alpha, (bf16_t*)out, HW, C, ppblk);
+    else if (dtype == MRISR_F16) norm_blend_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x0, scale0, shift0, (const f16_t*)x1, scale1, shift1, alpha, (f16_t*)out, HW, C, ppblk);
+    else if (dtype == MRISR_F32) norm_blend_kernel<float><<<grid, 256, 0, s>>>((const float*)x0, scale0, shift0, (const float*)x1, scale1, shift1, alpha, (float*)out, HW, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "norm_blend: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("norm_blend");
     return MRISR_OK;
@@ -1221,22 +1231,22 @@ int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int 
 // convolutions and their weight gradients run on the plain prefetching loader.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_pool2_kernel(const T* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, T* __restrict__ out, int N,
-                                                         int H, int W, int C) {
+                                                         const float* __restrict__ shift, T* __restrict__ out, int H, int W,
+                                                         int C, int pix_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    const int nvec = C / VEC, Ho = H / 2, Wo = W / 2;
-    const size_t total = (size_t)N * Ho * Wo * nvec;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int cv = idx % nvec;
-        size_t r = idx / nvec;
-        const int xo = r % Wo; r /= Wo;
-        const int yo = r % Ho;
-        const int n = r / Ho;
-        const int c = cv * VEC;
-        float sc[VEC], sh[VEC];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = C / VEC, ppb = 256 / nvec, Ho = H / 2, Wo = W / 2, HWo = Ho * Wo;
+    const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
+    if (pl >= ppb) return;
+    float sc[VEC], sh[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
-        const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
+    for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
+    const T* xb = x + (size_t)n * H * W * C + c;
+    T* ob = out + (size_t)n * HWo * C + c;
+    const int pend = min(HWo, (int)(blockIdx.x + 1) * pix_per_block);
+    for (int pp = blockIdx.x * pix_per_block + pl; pp < pend; pp += ppb) {
+        const int yo = pp / Wo, xo = pp - yo * Wo;
+        const T* b = xb + ((size_t)(2 * yo) * W + 2 * xo) * C;
         const Vec16<T> v00 = load_vec16(b), v01 = load_vec16(b + C), v10 = load_vec16(b + (size_t)W * C), v11 = load_vec16(b + (size_t)W * C + C);
         Vec16<T> o;
 #pragma unroll
@@ -1245,7 +1255,7 @@ __global__ __launch_bounds__(256) void norm_pool2_kernel(const T* __restrict__ x
             const float cq = lrelu(v10.get(e) * sc[e] + sh[e]), d = lrelu(v11.get(e) * sc[e] + sh[e]);
             o.set(e, fmaxf(fmaxf(a, bq), fmaxf(cq, d)));
         }
-        store_vec16(out + idx * VEC, o);
+        store_vec16(ob + (size_t)pp * C, o);
     }
 }
 
@@ -1253,12 +1263,15 @@ extern "C" int mrisr_norm_pool2(int dtype, const void* x, const float* scale, co
                                 int H, int W, int C, void* stream) {
     if (!x || !scale || !shift || !out) MRISR_FAIL(MRISR_E_ARG, "norm_pool2: null pointer");
     const int vec = mrisr_vec(dtype);
-    if (C % vec || H < 2 || W < 2) MRISR_FAIL(MRISR_E_SHAPE, "norm_pool2: C %d H %d W %d", C, H, W);
-    const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / vec);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == MRISR_BF16) norm_pool2_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, H, W, C);
-    else if (dtype == MRISR_F16) norm_pool2_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, scale, shift, (f16_t*)out, N, H, W, C);
-    else if (dtype == MRISR_F32) norm_pool2_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, H, W, C);
+    if (C % vec || C / vec > 256 || H < 2 || W < 2 || N <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "norm_pool2: N %d C %d H %d W %d", N, C, H, W);
+    const int nvec = C / vec, ppb = 256 / nvec, HWo = (H / 2) * (W / 2);
+    int ppblk = ppb * 16;
+    if (ppblk > HWo) ppblk = ceil_div(HWo, ppb) * ppb;
+    dim3 grid(ceil_div(HWo, ppblk), N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) norm_pool2_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, H, W, C, ppblk);
+    else if (dtype == MRISR_F16) norm_pool2_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, scale, shift, (f16_t*)out, H, W, C, ppblk);
+    else if (dtype == MRISR_F32) norm_pool2_kernel<float><<<grid, 256, 0, s>>>((const float*)x, scale, shift, (float*)out, H, W, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "norm_pool2: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("norm_pool2");
     return MRISR_OK;
@@ -1336,61 +1349,96 @@ extern "C" int mrisr_upsample2_stats(int dtype, const void* z_low, void* z, doub
     return MRISR_OK;
 }
 
-// adjoint: dz [N][2h][2w][C] -> dz_low [N][h][w][C]
+// adjoint: dz [N][2h][2w][C] -> dz_low [N][h][w][C].  One low-resolution pixel gathers a 4 x 4 neighbourhood of dz; as
+// one pixel per thread that is 16 vector loads per output and the pass is bound by the L1 / texture path (2.1 GB of
+// loads for a 537 MB tensor: 3 TB/s of HBM traffic).  Here a thread owns a 2 x 2 block of outputs: their 6 x 6
+// neighbourhood is read once, row by row (9 loads per output), reduced along x into the two output columns first and
+// then along y into the two output rows.  Block = (block range, image), thread = (block lane, 16-byte channel vector).
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restrict__ dz, T* __restrict__ dzl, int N,
-                                                                int h, int w, int C) {
+__global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const T* __restrict__ dz, T* __restrict__ dzl, int h, int w,
+                                                                int C, int blk_per_block) {
     constexpr int VEC = Vec16<T>::N;
-    const int nvec = C / VEC;
-    const size_t total = (size_t)N * h * w * nvec;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int cv = idx % nvec;
-        size_t r = idx / nvec;
-        const int x = r % w; r /= w;
-        const int y = r % h;
-        const int n = r / h;
-        int iy[kUpAdj], ix[kUpAdj];
-        float wy[kUpAdj], wx[kUpAdj];
-        up2_adjoint_weights(y, h, iy, wy);
-        up2_adjoint_weights(x, w, ix, wx);
-        float acc[VEC];
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = C / VEC, ppb = 256 / nvec, bw = (w + 1) >> 1, nblk = ((h + 1) >> 1) * bw;
+    const int cv = t % nvec, pl = t / nvec;
+    if (pl >= ppb) return;
+    const T* b = dz + (size_t)n * 4 * h * w * C + cv * VEC;
+    T* ob = dzl + (size_t)n * h * w * C + cv * VEC;
+    const int bend = min(nblk, (int)(blockIdx.x + 1) * blk_per_block);
+    for (int bi = blockIdx.x * blk_per_block + pl; bi < bend; bi += ppb) {
+        const int by = bi / bw, bx = bi - by * bw;
+        const int y0 = 2 * by, x0 = 2 * bx;
+        const bool vy1 = y0 + 1 < h, vx1 = x0 + 1 < w;
+        // candidate rows / columns of output i: 2(y0+i)-1 .. 2(y0+i)+2 = local index 2i .. 2i+3 of the 6 staged ones
+        int iy[2][kUpAdj], ix[2][kUpAdj];
+        float wy[2][kUpAdj], wx[2][kUpAdj];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-        const T* b = dz + (size_t)n * 4 * h * w * C + cv * VEC;
-        // branch-free: all 16 candidate taps are loaded (coordinates clamped into the image, zero weights for the
-        // ones that do not touch this pixel), row by row, so 4 independent loads are always in flight
+        for (int i = 0; i < 2; ++i) {
+            up2_adjoint_weights(min(y0 + i, h - 1), h, iy[i], wy[i]);
+            up2_adjoint_weights(min(x0 + i, w - 1), w, ix[i], wx[i]);
+        }
+        float acc[2][2][VEC];
 #pragma unroll
-        for (int a = 0; a < kUpAdj; ++a) {
-            const int Y = min(max(iy[a], 0), 2 * h - 1);
-            Vec16<T> d[kUpAdj];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < kUpAdj; ++q) {
-                const int X = min(max(ix[q], 0), 2 * w - 1);
-                d[q] = load_vec16(b + ((size_t)Y * (2 * w) + X) * C);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int Y = min(max(4 * by - 1 + r, 0), 2 * h - 1);       // clamped: out-of-image rows carry zero weights
+            Vec16<T> d[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int X = min(max(4 * bx - 1 + q, 0), 2 * w - 1);
+                d[q] = load_vec16(b + (size_t)(Y * (2 * w) + X) * C);
             }
+            float hx[2][VEC];
 #pragma unroll
-            for (int q = 0; q < kUpAdj; ++q) {
-                const float wv = wy[a] * wx[q];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += wv * d[q].get(e);
+                for (int e = 0; e < VEC; ++e) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < kUpAdj; ++k) v += wx[j][k] * d[2 * j + k].get(e);
+                    hx[j][e] = v;
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (r < 2 * i || r >= 2 * i + kUpAdj) continue;        // row r is candidate r - 2i of output row i
+                const float wv = wy[i][r - 2 * i];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[i][j][e] += wv * hx[j][e];
             }
         }
-        Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
-        store_vec16(dzl + idx * VEC, o);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if ((i && !vy1) || (j && !vx1)) continue;
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.set(e, acc[i][j][e]);
+                store_vec16(ob + (size_t)((y0 + i) * w + x0 + j) * C, o);
+            }
     }
 }
 
 extern "C" int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, int N, int h, int w, int C, void* stream) {
     if (!dz || !dz_low) MRISR_FAIL(MRISR_E_ARG, "upsample2_adjoint: null pointer");
     const int vec = mrisr_vec(dtype);
-    if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "upsample2_adjoint: C %d", C);
-    const size_t total = (size_t)N * h * w * (C / vec);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (dtype == MRISR_BF16) upsample2_adjoint_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)dz, (bf16_t*)dz_low, N, h, w, C);
-    else if (dtype == MRISR_F16) upsample2_adjoint_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)dz, (f16_t*)dz_low, N, h, w, C);
-    else if (dtype == MRISR_F32) upsample2_adjoint_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)dz_low, N, h, w, C);
+    if (C % vec || C / vec > 256 || N <= 0 || N > 65535 || h <= 0 || w <= 0 || (size_t)h * w >= (1u << 28))
+        MRISR_FAIL(MRISR_E_SHAPE, "upsample2_adjoint: N %d h %d w %d C %d", N, h, w, C);
+    const int nvec = C / vec, ppb = 256 / nvec, nblk = ((h + 1) / 2) * ((w + 1) / 2);
+    int ppblk = ppb * 4;             // 2 x 2 output blocks per workgroup
+    if (ppblk > nblk) ppblk = ceil_div(nblk, ppb) * ppb;
+    dim3 grid(ceil_div(nblk, ppblk), N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) upsample2_adjoint_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dz, (bf16_t*)dz_low, h, w, C, ppblk);
+    else if (dtype == MRISR_F16) upsample2_adjoint_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)dz, (f16_t*)dz_low, h, w, C, ppblk);
+    else if (dtype == MRISR_F32) upsample2_adjoint_kernel<float><<<grid, 256, 0, s>>>((const float*)dz, (float*)dz_low, h, w, C, ppblk);
     else MRISR_FAIL(MRISR_E_DTYPE, "upsample2_adjoint: dtype %d", dtype);
     MRISR_CHECK_LAUNCH("upsample2_adjoint");
     return MRISR_OK;
@@ -1401,37 +1449,80 @@ extern "C" int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, 
 // final_up_bilinear's 3x3 conv (unet_model.py:151-152).  Gathering 4 taps per element inside the conv loader of a
 // 32-channel-wide layer is load-bound, so here the interpolated activation is written once and the conv (and
 // its weight gradient) run on the plain prefetching loader.
+// Thread = (group, 16-byte channel vector); group (gy, gx), gy in [0, h], gx in [0, w], owns the output pixels
+// Y in {2gy-1, 2gy}, X in {2gx-1, 2gx}: both rows interpolate between the SAME two source rows (gy-1, gy) and both
+// columns between the same two source columns, so the group loads and activates 4 source vectors for its 4 outputs -
+// one GroupNorm+LeakyReLU evaluation per output element instead of four (as one output pixel per thread the pass was
+// VALU-bound: 24 instructions per element, 3.2 TB/s).  Coordinates and weights are aten's (up2_coord) per output
+// row / column; a group whose two rows (columns) do not share their source pair - fp32 rounding of the source
+// coordinate at the last row - falls back to one output at a time.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_upsample2_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, T* __restrict__ out, int N,
-                                                             int h, int w, int C, int pix_per_block) {
+                                                             int h, int w, int C, int grp_per_block) {
     constexpr int VEC = Vec16<T>::N;
     const int t = threadIdx.x, n = blockIdx.y;
-    const int nvec = C / VEC, ppb = 256 / nvec, H = 2 * h, W = 2 * w, HW = H * W;
+    const int nvec = C / VEC, ppb = 256 / nvec, H = 2 * h, W = 2 * w, gw = w + 1, ngrp = (h + 1) * gw;
     const int cv = t % nvec, pl = t / nvec, c = cv * VEC;
     if (pl >= ppb) return;
     float sc[VEC], sh[VEC];            // hoisted: one (n, channel vector) per thread
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sc[e] = scale[(size_t)n * C + c + e]; sh[e] = shift[(size_t)n * C + c + e]; }
     const T* b = x + (size_t)n * h * w * C + c;
-    T* ob = out + (size_t)n * HW * C + c;
-    const int pend = min(HW, (int)(blockIdx.x + 1) * pix_per_block);
-    for (int pix = blockIdx.x * pix_per_block + pl; pix < pend; pix += ppb) {
-        const int Y = pix / W, X = pix - Y * W;
-        int y0, y1, x0, x1;
-        float wy, wx;
-        up2_coord(Y, h, y0, y1, wy);
-        up2_coord(X, w, x0, x1, wx);
-        const Vec16<T> v00 = load_vec16(b + ((size_t)y0 * w + x0) * C), v01 = load_vec16(b + ((size_t)y0 * w + x1) * C);
-        const Vec16<T> v10 = load_vec16(b + ((size_t)y1 * w + x0) * C), v11 = load_vec16(b + ((size_t)y1 * w + x1) * C);
-        Vec16<T> o;
+    T* ob = out + (size_t)n * H * W * C + c;
+    auto act = [&](const T* src, float* a) {
+        const Vec16<T> v = load_vec16(src);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float a = lrelu(v00.get(e) * sc[e] + sh[e]), bq = lrelu(v01.get(e) * sc[e] + sh[e]);
-            const float cq = lrelu(v10.get(e) * sc[e] + sh[e]), d = lrelu(v11.get(e) * sc[e] + sh[e]);
-            o.set(e, (1.f - wy) * ((1.f - wx) * a + wx * bq) + wy * ((1.f - wx) * cq + wx * d));
+        for (int e = 0; e < VEC; ++e) a[e] = lrelu(v.get(e) * sc[e] + sh[e]);
+    };
+    const int gend = min(ngrp, (int)(blockIdx.x + 1) * grp_per_block);
+    for (int g = blockIdx.x * grp_per_block + pl; g < gend; g += ppb) {
+        const int gy = g / gw, gx = g - gy * gw;
+        int Y[2] = {2 * gy - 1, 2 * gy}, X[2] = {2 * gx - 1, 2 * gx};
+        const bool vy[2] = {Y[0] >= 0, Y[1] < H}, vx[2] = {X[0] >= 0, X[1] < W};
+        int y0[2], y1[2], x0[2], x1[2];
+        float wy[2], wx[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            up2_coord(min(max(Y[k], 0), H - 1), h, y0[k], y1[k], wy[k]);
+            up2_coord(min(max(X[k], 0), W - 1), w, x0[k], x1[k], wx[k]);
         }
-        store_vec16(ob + (size_t)pix * C, o);
+        const int ky = vy[0] ? 0 : 1, kx = vx[0] ? 0 : 1;        // the pair the group shares
+        const bool shared = (!vy[0] || !vy[1] || (y0[0] == y0[1] && y1[0] == y1[1])) &&
+                            (!vx[0] || !vx[1] || (x0[0] == x0[1] && x1[0] == x1[1]));
+        if (shared) {
+            float a00[VEC], a01[VEC], a10[VEC], a11[VEC];
+            act(b + (size_t)(y0[ky] * w + x0[kx]) * C, a00);
+            act(b + (size_t)(y0[ky] * w + x1[kx]) * C, a01);
+            act(b + (size_t)(y1[ky] * w + x0[kx]) * C, a10);
+            act(b + (size_t)(y1[ky] * w + x1[kx]) * C, a11);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!vy[i] || !vx[j]) continue;
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        o.set(e, (1.f - wy[i]) * ((1.f - wx[j]) * a00[e] + wx[j] * a01[e]) + wy[i] * ((1.f - wx[j]) * a10[e] + wx[j] * a11[e]));
+                    store_vec16(ob + (size_t)(Y[i] * W + X[j]) * C, o);
+                }
+        } else {
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    if (!vy[i] || !vx[j]) continue;
+                    float a00[VEC], a01[VEC], a10[VEC], a11[VEC];
+                    act(b + (size_t)(y0[i] * w + x0[j]) * C, a00);
+                    act(b + (size_t)(y0[i] * w + x1[j]) * C, a01);
+                    act(b + (size_t)(y1[i] * w + x0[j]) * C, a10);
+                    act(b + (size_t)(y1[i] * w + x1[j]) * C, a11);
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        o.set(e, (1.f - wy[i]) * ((1.f - wx[j]) * a00[e] + wx[j] * a01[e]) + wy[i] * ((1.f - wx[j]) * a10[e] + wx[j] * a11[e]));
+                    store_vec16(ob + (size_t)(Y[i] * W + X[j]) * C, o);
+                }
+        }
     }
 }
 
@@ -1441,10 +1532,11 @@ extern "C" int mrisr_norm_upsample2(int dtype, const void* x, const float* scale
     const int vec = mrisr_vec(dtype);
     if (C % vec) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d", C);
     if (C / vec > 256 || N <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: C %d N %d", C, N);
-    const int nvec = C / vec, ppb = 256 / nvec, HW = 4 * h * w;
-    int ppblk = ppb * 32;
-    if (ppblk > HW) ppblk = ceil_div(HW, ppb) * ppb;
-    dim3 grid(ceil_div(HW, ppblk), N);
+    if (h <= 0 || w <= 0 || (size_t)h * w >= (1u << 26)) MRISR_FAIL(MRISR_E_SHAPE, "norm_upsample2: h %d w %d", h, w);
+    const int nvec = C / vec, ppb = 256 / nvec, ngrp = (h + 1) * (w + 1);
+    int ppblk = ppb * 8;             // groups per block (4 output pixels each)
+    if (ppblk > ngrp) ppblk = ceil_div(ngrp, ppb) * ppb;
+    dim3 grid(ceil_div(ngrp, ppblk), N);
     if (dtype == MRISR_BF16) norm_upsample2_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, scale, shift, (bf16_t*)out, N, h, w, C, ppblk);
     else if (dtype == MRISR_F16) norm_upsample2_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const f16_t*)x, scale, shift, (f16_t*)out, N, h, w, C, ppblk);
     else if (dtype == MRISR_F32) norm_upsample2_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, scale, shift, (float*)out, N, h, w, C, ppblk);

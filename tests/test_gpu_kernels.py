@@ -557,8 +557,9 @@ def test_blend_alpha_grad_and_channel_sum(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-def test_norm_pool2_and_upsample2(dt):
-    n, c, h, w = 2, 32, 11, 19
+@pytest.mark.parametrize("shape", [(2, 32, 11, 19), (1, 16, 8, 8), (1, 8, 2, 5), (1, 8, 3, 2)])
+def test_norm_pool2_and_upsample2(dt, shape):
+    n, c, h, w = shape
     x = rnd(n, c, h, w, seed=85)
     sc, sh = gn_affine(n, c, 86)
     xd, scd, shd = U.nhwc(x, dt), sc.to(U.DEV), sh.to(U.DEV)
@@ -581,6 +582,28 @@ def test_norm_pool2_and_upsample2(dt):
     dzl = torch.empty((n, h, w, c), dtype=U.tdt(dt), device=U.DEV)
     L.call("mrisr_upsample2_adjoint", dt, dzd.data_ptr(), dzl.data_ptr(), n, h, w, c, U.stream())
     assert U.relerr(U.nchw(dzl), xr.grad) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 32, 11, 19), (1, 16, 1, 5), (1, 64, 32, 32), (1, 8, 256, 3)])
+def test_norm_upsample2(dt, shape):
+    """Materialised bilinear x2 (align_corners) of the activated tensor (unet_model.py:151): every output against
+    F.interpolate, including 1-pixel extents and the last row / column where the source coordinate rounds."""
+    n, c, h, w = shape
+    if c % (4 if dt == L.F32 else 8):
+        pytest.skip("channel count below the 16-byte vector")
+    x = rnd(n, c, h, w, seed=130)
+    sc, sh = gn_affine(n, c, 131)
+    xd, scd, shd = U.nhwc(x, dt), sc.to(U.DEV), sh.to(U.DEV)
+    out = torch.full((n, 2 * h, 2 * w, c), float("nan"), dtype=U.tdt(dt), device=U.DEV)
+    L.call("mrisr_norm_upsample2", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), out.data_ptr(), n, h, w, c, U.stream())
+    act = F.leaky_relu(U.rounded(x, dt) * sc.view(n, c, 1, 1) + sh.view(n, c, 1, 1), 0.2)
+    ref = F.interpolate(act, scale_factor=2, mode="bilinear", align_corners=True)
+    got = U.nchw(out)
+    assert torch.isfinite(got).all()
+    assert U.relerr(got, ref) <= TOL_OUT[dt]
+    if dt == L.F32:
+        assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
 
 
 # ------------------------------------------------------------------------------------------- adam / cast
