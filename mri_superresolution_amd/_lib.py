@@ -152,6 +152,16 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# Bumped by code that rewrites a tensor's bytes behind autograd's version counter (HIP-graph replays into static
+# buffers); caches keyed on (data_ptr, _version) compare it as well.
+inplace_epoch = 0
+
+
+def bump_inplace_epoch():
+    global inplace_epoch
+    inplace_epoch += 1
+
+
 _NUM_CUS = None
 
 

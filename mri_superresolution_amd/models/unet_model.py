@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.init as init
 
+from .. import _lib as _L
 from .. import standalone
 from ..engine import UNetEngine
 
@@ -313,6 +314,7 @@ class UNetSuperRes(nn.Module):
                 raise ValueError(f"graph captured for {tuple(static_in.shape)}, got {tuple(x.shape)}")
             static_in.copy_(x)
             graph.replay()
+            _L.bump_inplace_epoch()       # static_out was rewritten without a version bump
             return static_out
         run.graph = graph
         return run

@@ -149,6 +149,43 @@ def test_ssim_and_combined_loss_match_reference_golden(golden_dir):
         assert (x2.grad.cpu() - xr.grad).abs().max().item() <= 2e-4 * xr.grad.abs().max().item()
 
 
+def test_ssim_metric_after_loss_reuses_the_pass_and_stays_exact():
+    """train.py evaluates the SSIM metric on the tensors the loss has just seen: the second call is served from the
+    loss's per-plane sums - only while both operands are unchanged (address, autograd version, no graph replay)."""
+    from mri_superresolution_amd import _lib as L
+    from mri_superresolution_amd.utils import losses as LS
+    from mri_superresolution_amd.utils.losses import CombinedLoss, SSIM, ssim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    out = torch.rand(2, 1, 40, 56, generator=g).to(dev).requires_grad_(True)
+    tgt = torch.rand(2, 1, 40, 56, generator=g).to(dev)
+    crit, metric = CombinedLoss(ssim_weight=0.4, device=dev), SSIM(device=dev)
+    loss = crit(out, tgt)
+    cached = LS._last_sums
+    assert cached is not None
+    with torch.no_grad():
+        m1 = metric(out, tgt)
+    assert LS._last_sums is cached                       # no second kernel pass
+    LS._last_sums = None
+    with torch.no_grad():
+        m2 = metric(out, tgt)
+    assert m1.item() == m2.item()
+    loss.backward()
+    # an in-place change of either operand, or a graph replay, invalidates the entry
+    loss = crit(out, tgt)
+    with torch.no_grad():
+        tgt.mul_(0.5)
+        m3 = metric(out, tgt)
+        LS._last_sums = None
+        assert m3.item() == metric(out, tgt).item() and m3.item() != m1.item()
+    loss = crit(out, tgt)
+    entry = LS._last_sums
+    L.bump_inplace_epoch()
+    with torch.no_grad():
+        ssim(out, tgt)
+    assert LS._last_sums is not entry
+
+
 def test_loss_api_errors_and_edges():
     for bad in ((-0.1, 0.0), (0.0, 1.5), (0.7, 0.6)):
         with pytest.raises(ValueError):
