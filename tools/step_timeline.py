@@ -15,7 +15,7 @@ qcol = "queue_id" if "queue_id" in cols else ("queue" if "queue" in cols else No
 scol = "stream_id" if "stream_id" in cols else ("stream" if "stream" in cols else None)
 sel = "name, start, end" + (f", {qcol}" if qcol else ", 0") + (f", {scol}" if scol else ", 0")
 rows = list(db.execute(f"select {sel} from kernels order by start"))
-adam = [i for i, r in enumerate(rows) if "adam" in r[0]]
+adam = [i for i, r in enumerate(rows) if "adam" in r[0] and "advance" not in r[0]]
 if len(adam) < 2:
     sys.exit("fewer than two adam kernels in the trace")
 a, b = adam[-2], adam[-1]
