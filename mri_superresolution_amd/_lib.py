@@ -111,6 +111,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 210      # mrisr_version() of the library these struct layouts and signatures belong to
 
 
 def load():
@@ -129,6 +130,9 @@ def load():
         fn = getattr(lib, name)       # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
+    if not os.environ.get("MRISR_LIB") and int(lib.mrisr_version()) < ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} is version {int(lib.mrisr_version())}, these bindings need {ABI_VERSION} (struct layouts "
+                           "changed): rebuild with `python -m mri_superresolution_amd.build`")
     global STAT_SLOTS
     if hasattr(lib, "mrisr_stat_slots"):
         # the statistics arenas are sized with this: it must be the value the kernels were compiled with
