@@ -195,6 +195,8 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             pmask = mask;
         }
     };
+    // every source stored as-is (materialised pooled / up-sampled / blended inputs): no transform in the commit
+    const bool all_raw = p.src[0].mode == MRISR_SRC_RAW && (p.nsrc < 2 || p.src[1].mode == MRISR_SRC_RAW);
     auto commit = [&](char* buf, int n) {
         if (DBG(p) & 2) return;
         char* lds_dy = buf;
@@ -213,10 +215,12 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(const ConvPar
             for (int i = 0; i < kWgSlots; ++i) {
                 Vec16<T> v = ph[i][0];
                 if constexpr (NH == 1) {     // straight-line: y = x*sc+sh, act = max(y, slope*y)
+                    if (!all_raw) {          // (scalar branch: sources stored as-is go to LDS as loaded)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const float y = fmaf(v.get(e), sc[e], sh[e]);
-                        v.set(e, fmaxf(y, pslope * y));
+                        for (int e = 0; e < VEC; ++e) {
+                            const float y = fmaf(v.get(e), sc[e], sh[e]);
+                            v.set(e, fmaxf(y, pslope * y));
+                        }
                     }
                 } else {
                     float fa[VEC], fb[VEC];
