@@ -42,7 +42,7 @@ __global__ __launch_bounds__(THREADS) void loop(int iters, float* sink, unsigned
             return;
         }
     }
-    const char* base = (const char*)lds + wave * (NW == 100 ? 12288 : 16384);
+    const char* base = (const char*)lds + (THREADS == 1024 ? wave * 6144 : wave * (NW == 100 ? 12288 : 16384));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[NA][NB] = {};
     const int r = lane & 31, lh = lane >> 5;
@@ -52,7 +52,16 @@ __global__ __launch_bounds__(THREADS) void loop(int iters, float* sink, unsigned
     for (int it = 0; it < iters; ++it) {
         // NW x 1 KiB per K = 32 step landing in LDS beside the fragment reads (the kernels' operand staging: ~0.135 KB per
         // MFMA).  NW > 0: by LDS-DMA (global_load_lds_dwordx4 from an L2-resident buffer), NW < 0: by ds_write_b128
-        if constexpr (NW > 0) {
+        if constexpr (NW == 50) {          // 1 KiB per 8 MFMAs with 4 MFMAs per step: every second step
+            if (it & 1) {
+                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)((char*)lds + 98304 + (wave & 7) * 4096 + (it & 3) * 1024);
+                const char* g = gsrc + (size_t)((it * 16 + wave) & 1023) * 1024 + lane * 16;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane((int)dst)) : "memory");
+            }
+            if ((it & 15) == 15) __builtin_amdgcn_s_waitcnt(0x0f70);
+        } else if constexpr (NW > 0) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)((char*)lds + 98304 + wave * 4096 + ((it + w) & 3) * 1024);
@@ -94,7 +103,8 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     for (int round = 0; round < 4; ++round)
-        for (int v = 0; v < 8; ++v) {
+        for (int v = 0; v < 10; ++v) {
+            if (v == 7) continue;              // (un-paced loader waves: 48x slower, see profiles/NOTES.md R2-13)
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             int waves, na, nb, it = iters;
@@ -105,12 +115,14 @@ int main(int argc, char** argv) {
             else if (v == 4) { waves = 8; na = 2; nb = 4; it = iters / 2; loop<2, 4, 512, 2><<<cus, 512>>>(it, sink, stamps, gsrc); }
             else if (v == 5) { waves = 8; na = 2; nb = 2; loop<2, 2, 512, -1><<<cus, 512>>>(it, sink, stamps, gsrc); }
             else if (v == 6) { waves = 8; na = 2; nb = 4; it = iters / 2; loop<2, 4, 512, -2><<<cus, 512>>>(it, sink, stamps, gsrc); }
-            else { waves = 8; na = 2; nb = 2; loop<2, 2, 768, 100><<<cus, 768>>>(it, sink, stamps, gsrc); }
+            else if (v == 7) { waves = 8; na = 2; nb = 2; loop<2, 2, 768, 100><<<cus, 768>>>(it, sink, stamps, gsrc); }
+            else if (v == 8) { waves = 16; na = 1; nb = 2; it = iters * 2; loop<1, 2, 1024, 0><<<cus, 1024>>>(it, sink, stamps, gsrc); }
+            else { waves = 16; na = 1; nb = 2; it = iters * 2; loop<1, 2, 1024, 50><<<cus, 1024>>>(it, sink, stamps, gsrc); }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             unsigned long long h[2]; hipMemcpy(h, stamps, 16, hipMemcpyDeviceToHost);
             const double flops = 2.0 * (32.0 * na) * (32.0 * nb) * 32 * (double)it * waves * cus;
-            printf("round %d  %s wave tile %3d x %3d, %d waves: %.3f ms  %.1f TFLOP/s  clock %.3f GHz  %.1f cycles per MFMA per SIMD\n", round, v == 7 ? "+DMA waves " : (v >= 5 ? "+ds_write  " : (v >= 3 ? "+LDS-DMA   " : "           ")), 32 * na,
+            printf("round %d  %s wave tile %3d x %3d, %d waves: %.3f ms  %.1f TFLOP/s  clock %.3f GHz  %.1f cycles per MFMA per SIMD\n", round, v == 9 ? "+LDS-DMA   " : v == 8 ? "           " : v == 7 ? "+DMA waves " : (v >= 5 ? "+ds_write  " : (v >= 3 ? "+LDS-DMA   " : "           ")), 32 * na,
                    32 * nb, waves, ms, flops / ms / 1e9, h[0] / (h[1] / 100.0) / 1e3, (double)h[0] / it / (2.0 * na * nb) / (waves / 4));
         }
     return 0;
