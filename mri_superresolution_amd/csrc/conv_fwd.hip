@@ -1452,11 +1452,12 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     if (d->relu_mask && (d->out_mode != MRISR_OUT_PLAIN || d->Cout % (mrisr_vec(d->dtype))))
         MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask needs a plain output with Cout a multiple of the 16-byte vector");
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);
-    // narrow layers (the 32-channel 512 x 512 head) are bound by operand traffic, not by the matrix pipe: square
-    // 16 x 16 tiles (324-pixel halo, 18-pixel rows) instead of 8 x 32 (340, 34): 32 -> 32 at 512^2 167 -> 130 us, 64 -> 32 and
-    // 32 -> 64 3-5 % (wider layers: +-2 %; the weight-gradient kernel keeps 8 x 32, its fast paths are built on it)
+    // square 16 x 16 output tiles (324-pixel halo, 18-pixel rows) instead of 8 x 32 (340, 34): the kernels are bound by the
+    // operand bytes they stage (profiles/NOTES.md R2-13/14).  32 -> 32 at 512^2: 167 -> 130 us, 64 -> 32 / 32 -> 64: 3-5 %, wide
+    // layers +-2 % each, the training step -0.8 % with every 3x3 layer on 16 x 16 (A/B on one box).  The weight-gradient
+    // kernel keeps 8 x 32: its fast paths are built on it.
 #ifndef MRISR_NO_TILE16
-    if (d->ksize == 3 && d->W > 16 && d->H >= 16 && (d->Cin <= 32 || d->Cout <= 32)) {
+    if (d->ksize == 3 && d->W > 16 && d->H >= 16) {
         p.th = 16; p.tw_log2 = 4;
         p.tiles_x = ceil_div(d->W, 16); p.tiles_y = ceil_div(d->H, 16);
     }
