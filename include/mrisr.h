@@ -17,7 +17,7 @@
  *                no internal synchronisation; re-entrant.  Process-wide state is limited to
  *                once-initialised constants (CU count, per-kernel LDS-size attributes, both
  *                behind std::call_once / magic statics); the library reads no environment variable.
- *  - layout    : activations NHWC ("channels last"), dtype MRISR_BF16 or MRISR_F32;
+ *  - layout    : activations NHWC ("channels last"), dtype MRISR_F32, MRISR_BF16 or MRISR_F16;
  *                conv weights [Cout][kh][kw][Cin] fp32 masters (= torch channels_last
  *                storage of a (Cout,Cin,kh,kw) tensor); statistics double / fp32.
  */
@@ -72,7 +72,7 @@ typedef struct {
 } mrisr_src;
 
 typedef struct {
-    int32_t dtype;          /* MRISR_F32 | MRISR_BF16 (storage type of src/out/packed weights) */
+    int32_t dtype;          /* MRISR_F32 | MRISR_BF16 | MRISR_F16 (storage of src/out/packed weights) */
     int32_t N, H, W;        /* conv input (= output) spatial size                              */
     int32_t Cin, Cout;
     int32_t ksize;          /* 1 or 3 (padding ksize/2, stride 1)                              */

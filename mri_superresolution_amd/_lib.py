@@ -5,8 +5,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+from .tuning import TUNING
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MRISR_LIB") or os.path.join(_HERE, "libmrisr.so")   # MRISR_LIB: A/B builds (tuning)
+LIB_PATH = TUNING.lib_path or os.path.join(_HERE, "libmrisr.so")   # MRISR_LIB: A/B builds (tuning.py); same checks apply
 
 F32, BF16, F16 = 0, 1, 2
 SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
@@ -124,19 +126,21 @@ def load():
             f"{LIB_PATH} not found: the HIP kernel library is not built. Run "
             "`python -m mri_superresolution_amd.build` (needs hipcc); there is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    # the same checks for the in-tree library and for an MRISR_LIB build: every declared symbol present, ABI version equal
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} lacks {len(missing)} symbol(s) of include/mrisr.h ({', '.join(missing[:4])}...): "
+                           "header/library drift - rebuild with `python -m mri_superresolution_amd.build`")
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("MRISR_LIB") and not hasattr(lib, name):
-            continue                  # A/B build of an older revision (tuning only)
-        fn = getattr(lib, name)       # AttributeError here = header/library drift
+        fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if not os.environ.get("MRISR_LIB") and int(lib.mrisr_version()) < ABI_VERSION:
+    if int(lib.mrisr_version()) != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} is version {int(lib.mrisr_version())}, these bindings need {ABI_VERSION} (struct layouts "
                            "changed): rebuild with `python -m mri_superresolution_amd.build`")
     global STAT_SLOTS
-    if hasattr(lib, "mrisr_stat_slots"):
-        # the statistics arenas are sized with this: it must be the value the kernels were compiled with
-        STAT_SLOTS = int(lib.mrisr_stat_slots())
+    # the statistics arenas are sized with this: it must be the value the kernels were compiled with
+    STAT_SLOTS = int(lib.mrisr_stat_slots())
     _lib = lib
     return lib
 

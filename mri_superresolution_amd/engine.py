@@ -11,7 +11,6 @@ concat, pixel-shuffle and the alpha blend live inside the convolution loaders/ep
 """
 from __future__ import annotations
 
-import os
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -19,6 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib as L
+from .tuning import TUNING
 
 GN_GROUPS = 8
 GN_EPS = 1e-5
@@ -34,22 +34,17 @@ def _dt(dtype: torch.dtype) -> int:
     raise ValueError(f"unsupported compute dtype {dtype} (use torch.float32, torch.float16 or torch.bfloat16)")
 
 
-# order of the two convolutions of a layer's backward step (tuning: MRISR_WGRAD_LAST=1 runs dgrad first)
-_WGRAD_LAST = os.environ.get("MRISR_WGRAD_LAST", "0") == "1"
-# weight-gradient kernels on a second HIP stream (they hang off the backward chain: nothing downstream reads dW before the
-# optimiser step), so that they fill the launch-boundary gaps and memory-bound stretches of the main stream
+# Schedule knobs (defaults = the measured optimum; tuning.py reads the MRISR_* overrides once, for A/B runs on one box):
+# weight-gradient kernels run on a second, high-priority HIP stream (they hang off the backward chain: nothing
+# downstream reads dW before the optimiser step), the chip split in half between the two kinds of convolution
 # (measured at C2 on one box, A/B alternating: one stream 9.70 ms/step; second stream, every kernel sized for the whole
-# chip 9.52; second stream + half the CUs each 9.31 (64 CUs for the weight gradients: 10.8, 96: 9.35, 144: 9.36-9.49,
-# 160: 9.58, 192: 10.8) - MRISR_WGRAD_STREAM=0 / MRISR_WGRAD_CUS=k override for A/B runs)
-_WGRAD_STREAM = os.environ.get("MRISR_WGRAD_STREAM", "1") == "1"
-# CUs given to the second stream's weight-gradient kernels; the backward chain's convolutions are sized for the rest
-# (0 = no split: every persistent kernel is sized for the whole chip and the two streams take turns; -1 = half)
-_WGRAD_CUS = int(os.environ.get("MRISR_WGRAD_CUS", "-1"))
-# tuning: size every persistent convolution for this many CUs (two independent steps side by side on one GPU)
-_CU_LIMIT = int(os.environ.get("MRISR_CU_LIMIT", "0"))
-# (also tried: input gradient first on the whole chip, the weight gradient behind it on 128-224 CUs so that it overlaps the
-# next node's memory-bound GroupNorm-backward passes instead of the input gradient: 9.33-9.41 ms/step, no better than the
-# half / half split's 9.37-9.39 on the same box - the two kinds of kernel also compete for HBM and for the power budget)
+# chip 9.52; second stream + half the CUs each 9.31; 64 CUs for the weight gradients: 10.8, 96: 9.35, 144: 9.36-9.49,
+# 160: 9.58, 192: 10.8; input gradient first on the whole chip with the weight gradient behind it on 128-224 CUs:
+# 9.33-9.41 - the two kinds of kernel also compete for HBM and for the power budget).
+_WGRAD_LAST = TUNING.wgrad_last
+_WGRAD_STREAM = TUNING.wgrad_stream
+_WGRAD_CUS = TUNING.wgrad_cus
+_CU_LIMIT = TUNING.cu_limit
 
 
 @dataclass
@@ -504,7 +499,7 @@ class UNetEngine:
                 # high priority = its own hardware queue class: with RCCL's streams around, a normal-priority second
                 # stream was mapped onto the main stream's hardware queue (GPU_MAX_HW_QUEUES = 4 by default) and the
                 # cross-stream waits serialised the step (measured 12.0 instead of 9.5 ms under data parallelism)
-                side = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MRISR_SIDE_PRIO", "-1")))
+                side = self._side_stream = torch.cuda.Stream(device=dev, priority=TUNING.side_prio)
         user_hook = bucket_hook
         if bucket_hook is not None and side is not None:
             def bucket_hook(name):     # noqa: F811

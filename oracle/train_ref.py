@@ -15,10 +15,11 @@ from .losses_ref import combined_loss, ssim
 from .unet_ref import unet_forward
 
 
-def loss_and_grads(sd, low, high, ssim_weight=0.4, perceptual_weight=0.0, depth=4):
-    """Autograd through the functional restatement: returns (output, loss, grads dict)."""
+def loss_and_grads(sd, low, high, ssim_weight=0.4, perceptual_weight=0.0, depth=4, gates=None, record=None):
+    """Autograd through the functional restatement: returns (output, loss, grads dict).
+    ``gates`` / ``record``: forced / recorded LeakyReLU and max-pool decisions (unet_ref.unet_forward)."""
     params = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in sd.items())
-    out = unet_forward(params, low, depth=depth)
+    out = unet_forward(params, low, depth=depth, gates=gates, record=record)
     loss = combined_loss(out, high, ssim_weight, perceptual_weight)
     grads = torch.autograd.grad(loss, list(params.values()))
     return out.detach(), loss.detach(), OrderedDict(zip(params.keys(), grads))

@@ -110,48 +110,77 @@ def kaiming_state_dict(base_filters: int, seed: int = 0, in_channels: int = 1,
 
 
 # --------------------------------------------------------------------------- ops
-def _gn_lrelu(x, w, b):
+def _gn_lrelu(x, w, b, key=None, gates=None, record=None):
     # GroupNorm(8, C) -> LeakyReLU(0.2)          (unet_model.py:30-31 and siblings)
-    return F.leaky_relu(F.group_norm(x, GN_GROUPS, w, b, GN_EPS), LRELU_SLOPE)
+    # gates / record (test infrastructure, see unet_forward): the network is piecewise linear; ``record`` receives the
+    # LeakyReLU branch taken by every element (y > 0), ``gates`` FORCES the branches of another forward instead of
+    # deciding them from this forward's own y (the slope then multiplies y whatever its sign).
+    y = F.group_norm(x, GN_GROUPS, w, b, GN_EPS)
+    if record is not None:
+        record["lrelu:" + key] = y.detach() > 0
+    if gates is not None:
+        m = gates["lrelu:" + key]
+        return y * torch.where(m, torch.ones((), dtype=y.dtype), torch.full((), LRELU_SLOPE, dtype=y.dtype))
+    return F.leaky_relu(y, LRELU_SLOPE)
 
 
-def _double_conv(sd, p, x, taps=None):
+def _pool2(x, key=None, gates=None, record=None):
+    # MaxPool2d(2)                                   (unet_model.py:52)
+    if gates is not None:      # forced arg-max (flat index into the H*W plane, as max_pool2d's return_indices)
+        idx = gates["pool:" + key]
+        n, c, h, w = x.shape
+        return x.flatten(2).gather(2, idx.flatten(2)).view(n, c, h // 2, w // 2)
+    if record is not None:
+        out, idx = F.max_pool2d(x, 2, return_indices=True)
+        record["pool:" + key] = idx
+        return out
+    return F.max_pool2d(x, 2)
+
+
+def _double_conv(sd, p, x, taps=None, gates=None, record=None):
     # (conv3x3 no-bias -> GN -> LReLU) x 2           (unet_model.py:27-38)
     y = F.conv2d(x, sd[f"{p}.double_conv.0.weight"], None, padding=1)
     if taps is not None:
         taps[f"{p}.double_conv.0"] = y
-    x = _gn_lrelu(y, sd[f"{p}.double_conv.1.weight"], sd[f"{p}.double_conv.1.bias"])
+    x = _gn_lrelu(y, sd[f"{p}.double_conv.1.weight"], sd[f"{p}.double_conv.1.bias"], f"{p}.double_conv.0", gates, record)
     y = F.conv2d(x, sd[f"{p}.double_conv.3.weight"], None, padding=1)
     if taps is not None:
         taps[f"{p}.double_conv.3"] = y
-    return _gn_lrelu(y, sd[f"{p}.double_conv.4.weight"], sd[f"{p}.double_conv.4.bias"])
+    return _gn_lrelu(y, sd[f"{p}.double_conv.4.weight"], sd[f"{p}.double_conv.4.bias"], f"{p}.double_conv.3", gates, record)
 
 
-def _up(sd, p, x1, x2, taps=None):
+def _up(sd, p, x1, x2, taps=None, gates=None, record=None):
     # bilinear x2 (align_corners) -> 1x1 conv -> GN -> LReLU -> pad -> cat[skip, up] -> DoubleConv
     #                                                (unet_model.py:70-75, 80-94)
     x1 = F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True)
     y = F.conv2d(x1, sd[f"{p}.up.1.weight"], None)
     if taps is not None:
         taps[f"{p}.up.1"] = y
-    x1 = _gn_lrelu(y, sd[f"{p}.up.2.weight"], sd[f"{p}.up.2.bias"])
+    x1 = _gn_lrelu(y, sd[f"{p}.up.2.weight"], sd[f"{p}.up.2.bias"], f"{p}.up.1", gates, record)
     dy = x2.shape[2] - x1.shape[2]
     dx = x2.shape[3] - x1.shape[3]
     if dy != 0 or dx != 0:
         x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-    return _double_conv(sd, f"{p}.conv", torch.cat([x2, x1], dim=1), taps)
+    return _double_conv(sd, f"{p}.conv", torch.cat([x2, x1], dim=1), taps, gates, record)
 
 
-def unet_forward(sd, x, taps=None, depth: int = 4):
+def unet_forward(sd, x, taps=None, depth: int = 4, gates=None, record=None):
     """``UNetSuperRes.forward`` (unet_model.py:189-211).  ``taps`` (optional dict) receives
     the raw (pre-GroupNorm) output of every convolution plus the stage activations.
-    ``depth`` != 4: the build's extension (see state_dict_spec)."""
-    xs = [_double_conv(sd, "inc", x, taps)]
+    ``depth`` != 4: the build's extension (see state_dict_spec).
+
+    ``record`` / ``gates`` (optional dicts, test infrastructure): the network is piecewise linear in its activations -
+    every LeakyReLU picks one of two slopes, every MaxPool2d one of four inputs.  ``record`` receives those decisions
+    (``"lrelu:<conv key>"``: bool tensor y > 0 in NCHW, the pixel-shuffled node in its shuffled layout;
+    ``"pool:down<k>"``: arg-max indices as ``F.max_pool2d(..., return_indices=True)``); ``gates`` forces the decisions
+    of ANOTHER forward (e.g. the HIP path's, tests/hiputil.hip_gates) so that two finite-precision implementations
+    are compared on the same linear piece (tests/test_gpu_fullwidth.py, tools/c5_diag.py)."""
+    xs = [_double_conv(sd, "inc", x, taps, gates, record)]
     for k in range(1, depth):
-        xs.append(_double_conv(sd, f"down{k}.maxpool_conv.1", F.max_pool2d(xs[-1], 2), taps))
+        xs.append(_double_conv(sd, f"down{k}.maxpool_conv.1", _pool2(xs[-1], f"down{k}", gates, record), taps, gates, record))
     u = xs[-1]
     for j in range(1, depth):
-        u = _up(sd, f"up{j}", u, xs[depth - 1 - j], taps)
+        u = _up(sd, f"up{j}", u, xs[depth - 1 - j], taps, gates, record)
     x1 = xs[0]
     x2 = xs[1] if depth > 1 else None
     x3 = xs[2] if depth > 2 else None
@@ -159,15 +188,16 @@ def unet_forward(sd, x, taps=None, depth: int = 4):
     # dual-branch 2x head (unet_model.py:150-158, 202-207)
     yb = F.conv2d(F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=True),
                   sd["final_up_bilinear.1.weight"], None, padding=1)
-    xb = _gn_lrelu(yb, sd["final_up_bilinear.2.weight"], sd["final_up_bilinear.2.bias"])
+    xb = _gn_lrelu(yb, sd["final_up_bilinear.2.weight"], sd["final_up_bilinear.2.bias"], "final_up_bilinear.1", gates, record)
     yc = F.conv2d(u, sd["final_up_pixelshuffle.conv.weight"],
                   sd["final_up_pixelshuffle.conv.bias"], padding=1)
     yp = F.pixel_shuffle(yc, 2)                    # out[c,2h+i,2w+j] = in[4c+2i+j,h,w]
-    xp = _gn_lrelu(yp, sd["final_up_pixelshuffle.norm.weight"], sd["final_up_pixelshuffle.norm.bias"])
+    xp = _gn_lrelu(yp, sd["final_up_pixelshuffle.norm.weight"], sd["final_up_pixelshuffle.norm.bias"],
+                   "final_up_pixelshuffle.conv", gates, record)
     a = torch.sigmoid(sd["alpha"])
     xm = a * xb + (1 - a) * xp
     yf = F.conv2d(xm, sd["final_conv.0.weight"], None, padding=1)
-    xf = _gn_lrelu(yf, sd["final_conv.1.weight"], sd["final_conv.1.bias"])
+    xf = _gn_lrelu(yf, sd["final_conv.1.weight"], sd["final_conv.1.bias"], "final_conv.0", gates, record)
     yo = F.conv2d(xf, sd["final_conv.3.weight"], sd["final_conv.3.bias"])
     if taps is not None:
         taps.update({k: v for k, v in (("x1", x1), ("x2", x2), ("x3", x3), ("x4", x4)) if v is not None})

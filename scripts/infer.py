@@ -282,7 +282,8 @@ def parse_args(argv=None):
     p.add_argument("--base_filters", type=int, default=64)
     p.add_argument("--show_comparison", action="store_true")
     p.add_argument("--show_diff", action="store_true")
-    p.add_argument("--cpu", action="store_true", help="accepted for CLI compatibility; not supported (GPU-only build)")
+    p.add_argument("--cpu", action="store_true", help="REFUSED: accepted only so that the reference's command lines parse; this build runs on an MI355X through "
+                        "libmrisr.so only and exits with an error when --cpu is given (there is no CPU fallback)")
     p.add_argument("--use_amp", action="store_true", help="fp16 MFMA compute (the reference's autocast)")
     p.add_argument("--batch_size", type=int, default=16, help="(extension) images per forward in directory mode")
     p.add_argument("--io_workers", type=int, default=8, help="(extension) PNG decode / encode threads in directory mode")

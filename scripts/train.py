@@ -319,7 +319,8 @@ def parse_args(argv=None):
                         "device (utils/gpu_augment.DevicePairLoader) instead of DataLoader workers + PIL")
     p.add_argument("--amp_dtype", type=str, default="fp16", choices=["fp16", "bf16"],
                    help="(extension) autocast dtype of --use_amp: fp16 as the reference, or bf16 without loss scaling")
-    p.add_argument("--cpu", action="store_true", help="accepted for CLI compatibility; not supported (GPU-only build)")
+    p.add_argument("--cpu", action="store_true", help="REFUSED: accepted only so that the reference's command lines parse; this build runs on an MI355X through "
+                        "libmrisr.so only and exits with an error when --cpu is given (there is no CPU fallback)")
     p.add_argument("--checkpoint_dir", type=str, default="./checkpoints")
     p.add_argument("--log_dir", type=str, default="./logs")
     return p.parse_args(argv)

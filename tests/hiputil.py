@@ -150,3 +150,22 @@ def conv_wgrad(dt, srcs, dy_nchw, cout, cin, H, W, ks, combine=L.COMBINE_CONCAT,
 def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max |b|."""
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def hip_gates(out: torch.Tensor, depth: int = 4) -> dict:
+    """The piecewise-linear decisions of the HIP training forward that produced ``out`` (call BEFORE backward): per
+    GroupNorm node the LeakyReLU branch mask y > 0 with y = fma(raw, scale, shift) as the kernels evaluate it, and per
+    Down block the 2x2 arg-max of the activated tensor - in the layout oracle.unet_ref.unet_forward(gates=...) takes.
+    fp32 compute dtype only (16-bit paths round the activated value before it is compared)."""
+    saved = out.grad_fn.saved
+    gates, acts = {}, {}
+    for name, (n, h, w, raw, scale, shift, _) in saved["nodes"].items():
+        c = raw.shape[-1]
+        y = torch.addcmul(shift.view(n, 1, 1, c), raw.float(), scale.view(n, 1, 1, c)).permute(0, 3, 1, 2)
+        gates["lrelu:" + name] = (y > 0).cpu()
+        acts[name] = F.leaky_relu(y, 0.2)
+    for k in range(1, depth):
+        src = "inc.double_conv.3" if k == 1 else f"down{k - 1}.maxpool_conv.1.double_conv.3"
+        _, idx = F.max_pool2d(acts[src].contiguous(), 2, return_indices=True)
+        gates[f"pool:down{k}"] = idx.cpu()
+    return gates

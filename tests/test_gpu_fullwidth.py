@@ -7,8 +7,10 @@ at model level and not only timed by bench.py.
       loss <= 2e-5, every gradient <= 5e-4 of its max); bf16: PSNR / SSIM to 3 s.f. + gradient cosine / norm ratio
   C3  C2 shapes, N=1, + VGG19 perceptual 0.1 vs the oracle - PARITY UNPINNED (random VGG19 weights: torchvision and its
       ImageNet weights are absent offline, the reference holds no fixture; see tests/test_gpu_vgg.py)
-  C5  base_filters=128, depth 5 (extension, unpinned by the reference): 128^2, N=1 vs the float64 oracle, plus a
-      512^2 -> 1024^2 property run (finite, in [0,1], fp32 forward bitwise reproducible)
+  C5  base_filters=128, depth 5 (extension, unpinned by the reference): 128^2, N=1 vs the float64 oracle in fp32
+      (gradients on the SAME linear piece: the HIP forward's LeakyReLU / max-pool decisions forced into the oracle) and
+      in fp16 (configs[4]'s dtype), a 512^2 -> 1024^2 property run (finite, in [0,1], fp32 forward bitwise
+      reproducible) and one 512^2 batch-8 fp16 train step through GradScaler
 
 The oracle side runs on the host cores in seconds to a minute per case (the f=64 256^2 N=2 float64 step is the slowest).
 """
@@ -28,6 +30,7 @@ from oracle.bf16_emul import cos_ratio, emulated_grads                    # noqa
 from oracle.inputs import make_pair                                       # noqa: E402
 from oracle.train_ref import loss_and_grads, train_steps                  # noqa: E402
 from oracle.unet_ref import formula_state_dict, unet_forward              # noqa: E402
+from hiputil import hip_gates                                             # noqa: E402
 
 
 def _report(line):
@@ -170,40 +173,57 @@ def test_c3_width_perceptual_term_unpinned():
             f"{float(loss_ref):.6f}, worst grad rel L2 {worst:.2e}")
 
 
-def test_c5_depth5_f128_vs_oracle_and_properties():
-    """BASELINE configs[4]: base_filters=128, depth 5 (this build's extension; unpinned by the reference)."""
+@pytest.fixture(scope="module")
+def c5_reference():
+    """float64 oracle of BASELINE configs[4]'s architecture (f=128, depth 5) at 128^2, N=1, shared by the fp32 and fp16
+    tests, with the oracle's own LeakyReLU / max-pool decisions recorded."""
     f, depth, seed = 128, 5, 8
     sd = formula_state_dict(f, seed, depth=depth)
     low, high = make_pair(1, 128, 128, seed)
-    ref_out, ref_loss, ref_grads = loss_and_grads(_f64(sd), low.double(), high.double(), 0.4, depth=depth)
+    own = {}
+    out, loss, grads = loss_and_grads(_f64(sd), low.double(), high.double(), 0.4, depth=depth, record=own)
+    return dict(f=f, depth=depth, seed=seed, sd=sd, low=low, high=high, out=out, loss=loss, grads=grads, own=own)
+
+
+def test_c5_depth5_f128_vs_oracle_and_properties(c5_reference):
+    """BASELINE configs[4]: base_filters=128, depth 5 (this build's extension; unpinned by the reference), fp32."""
+    r = c5_reference
+    f, depth, seed, sd, low, high = r["f"], r["depth"], r["seed"], r["sd"], r["low"], r["high"]
+    ref_out, ref_loss, ref_grads = r["out"], r["loss"], r["grads"]
     m = UNetSuperRes(1, 1, f, depth=depth)
     m.load_state_dict(sd)
     m = m.cuda().set_compute_dtype(torch.float32).train()
     out = m(low.cuda())
+    gates = hip_gates(out, depth)         # the HIP forward's LeakyReLU branches / pooling arg-max (before backward frees them)
     loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(out, high.cuda())
     loss.backward()
     rel = ((out.detach().cpu().double() - ref_out).abs() / ref_out.abs().clamp_min(1e-3)).max().item()
     assert rel <= 1e-3, rel
     assert abs(loss.item() - float(ref_loss)) <= 2e-5
-    # Gradient criterion at this width / depth (26 convs, K up to 18432, 1e8 activations): relative L2 <= 5e-3 per tensor
-    # and at most 1 % of a tensor's elements further than 5e-4 of its max from the float64 oracle.  A max-abs gate is
-    # not meaningful here: the network is piecewise linear, and two finite-precision forwards gate a handful of the
-    # near-zero LeakyReLU / max-pool inputs differently; in the deep layers (16x16 and 8x8 planes) one such flip moves a
-    # channel's bias gradient by percents and a weight-gradient row with it (measured: 2 of 1024 elements of
-    # up1.conv.double_conv.1.bias at 1.3e-2, everything else < 5e-4; relative L2 1.0-1.8e-3 from there down).  The
-    # torch-CPU fp32 oracle itself sits at relative L2 1-3e-4 / max 4e-4 from its float64 run, in different layers for 1
-    # and 8 threads, i.e. it depends on the summation order in the same way.
-    worst_l2, worst_frac = 0.0, 0.0
+    # The network is piecewise linear.  Two finite-precision forwards put a handful of the ~1e8 near-zero LeakyReLU /
+    # max-pool inputs on different sides, and in the deep layers (16x16 and 8x8 planes) ONE such flip moves a channel's
+    # bias gradient by percents and a weight-gradient row with it: against the oracle's OWN decisions the gradients
+    # sit at relative L2 1-2e-3 (profiles/r02_c5_fp32_gradient_noise.txt).  That explanation is CHECKED here: with the
+    # HIP forward's decisions forced into the float64 oracle (same linear piece on both sides) every gradient must
+    # meet the gate every other configuration meets - 5e-4 of its max, no exemption for small tensors
+    # (profiles/r03_c5_mask_forced.txt: measured numbers for both comparisons).
+    _, f_loss, f_grads = loss_and_grads(_f64(sd), low.double(), high.double(), 0.4, depth=depth, gates=gates)
+    nflip = sum(int((gates[k] != r["own"][k]).sum()) for k in gates)
+    assert abs(loss.item() - float(f_loss)) <= 2e-5
+    worst_forced, worst_l2 = 0.0, 0.0
     for k, p in m.named_parameters():
-        r = ref_grads[k]
-        d = p.grad.cpu().double() - r
-        l2 = d.norm().item() / max(r.norm().item(), 1e-30)
-        frac = (d.abs() > 5e-4 * r.abs().max().item() + 1e-6).double().mean().item()
-        worst_l2, worst_frac = max(worst_l2, l2), max(worst_frac, frac)
+        g = p.grad.cpu().double()
+        fr = f_grads[k]
+        err = (g - fr).abs().max().item()
+        worst_forced = max(worst_forced, err / (fr.abs().max().item() + 2e-3))
+        assert err <= 5e-4 * fr.abs().max().item() + 1e-6, f"{k}: err {err:.3e} vs max {fr.abs().max().item():.3e} (decisions forced)"
+        # against the oracle's own decisions: a loose sanity bound only (see above)
+        l2 = (g - ref_grads[k]).norm().item() / max(ref_grads[k].norm().item(), 1e-30)
+        worst_l2 = max(worst_l2, l2)
         assert l2 <= 5e-3, f"{k}: relative L2 {l2:.3e}"
-        assert frac <= 0.01 or r.numel() < 4096, f"{k}: {frac:.3e} of the elements beyond 5e-4 of max"
     _report(f"C5 f=128 depth=5 128x128 N=1 fp32 vs f64 oracle: out rel err {rel:.2e}, loss err "
-            f"{abs(loss.item() - float(ref_loss)):.2e}, worst grad rel L2 {worst_l2:.2e}, worst fraction beyond 5e-4 of max {worst_frac:.2e}")
+            f"{abs(loss.item() - float(ref_loss)):.2e}; {nflip} decisions differ; worst grad err/(max+2e-3) with the HIP "
+            f"decisions forced {worst_forced:.2e}; worst rel L2 against the oracle's own decisions {worst_l2:.2e}")
     # full C5 plane size: properties only (the CPU oracle would need minutes): finite, in [0,1], bitwise run-to-run
     m.eval()
     big, _ = make_pair(1, 512, 512, seed + 1)
@@ -217,6 +237,78 @@ def test_c5_depth5_f128_vs_oracle_and_properties():
     with torch.no_grad():
         ob = m(big.cuda())
     assert torch.isfinite(ob).all() and losses_ref.psnr(ob.cpu(), o1.cpu()) >= 35.0
+
+
+def test_c5_depth5_f128_fp16_vs_oracle(c5_reference):
+    """BASELINE configs[4] in ITS dtype: f=128, depth 5, fp16 storage + f16 MFMA at 128^2, N=1 against the float64
+    oracle - PSNR / SSIM vs the HR target to 3 s.f., >= 45 dB against the fp32 output, gradients (loss scale 65536 =
+    GradScaler's initial scale) by cosine / norm ratio with the per-parameter expectation of the CPU emulation of the
+    same storage points, as tests/test_gpu_fp16.py does at f=16."""
+    r = c5_reference
+    f, depth, seed, sd, low, high = r["f"], r["depth"], r["seed"], r["sd"], r["low"], r["high"]
+    scale = 65536.0
+    m = UNetSuperRes(1, 1, f, depth=depth)
+    m.load_state_dict(sd)
+    m = m.cuda().set_compute_dtype(torch.float32).eval()
+    with torch.no_grad():
+        out32 = m(low.cuda()).cpu()
+    m.set_compute_dtype(torch.float16).train()
+    out = m(low.cuda())
+    loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(out, high.cuda())
+    (loss * scale).backward()
+    o, ref = out.detach().cpu(), r["out"].float()
+    a, b = losses_ref.psnr(o, high), losses_ref.psnr(ref, high)
+    assert abs(a - b) <= 5e-3 * abs(b), (a, b)
+    a, b = float(losses_ref.ssim(o, high)), float(losses_ref.ssim(ref, high))
+    assert abs(a - b) <= 1e-3, (a, b)
+    p32 = losses_ref.psnr(o, out32)
+    assert p32 >= 45.0 and float(losses_ref.ssim(o, out32)) >= 0.999, p32
+    assert abs(loss.item() - float(r["loss"])) <= 1e-3 * float(r["loss"])
+    assert torch.isfinite(m.flat_grads).all()
+    emu, _ = emulated_grads(sd, low, high, 0.4, depth=depth, dtype=torch.float16, grad_scale=scale)
+    worst = 1.0
+    for k, p in m.named_parameters():
+        cos, ratio = cos_ratio(p.grad.cpu() / scale, r["grads"][k])
+        ecos, eratio = cos_ratio(emu[k], r["grads"][k])
+        worst = min(worst, cos)
+        assert cos >= min(0.98, ecos - 0.02), f"{k}: cosine {cos:.4f} (emulated {ecos:.4f})"
+        band = 0.6 if p.numel() == 1 else 0.10 + abs(eratio - 1.0)
+        assert abs(ratio - 1.0) <= band, f"{k}: norm ratio {ratio:.3f} (emulated {eratio:.3f})"
+    _report(f"C5 f=128 depth=5 128x128 N=1 fp16 vs f64 oracle: PSNR vs fp32 output {p32:.1f} dB, loss err "
+            f"{abs(loss.item() - float(r['loss'])):.2e}, worst gradient cosine {worst:.4f}")
+
+
+def test_c5_full_size_fp16_gradscaler_step():
+    """BASELINE configs[4] at its own size and batch: f=128, depth 5, 512^2 -> 1024^2, batch 8, fp16 autocast +
+    GradScaler (scripts/train.py:303-311) - one whole train step: finite loss and gradients, the step taken (count 1,
+    weights moved), the scale untouched at 65536 (no overflow).  Properties only: the CPU oracle needs ~10 minutes here."""
+    f, depth, n, s, seed = 128, 5, 8, 512, 9
+    m = UNetSuperRes(1, 1, f, depth=depth)
+    m.load_state_dict(formula_state_dict(f, seed, depth=depth))
+    m = m.cuda().train()                      # compute dtype follows autocast (fp16)
+    opt = FusedAdam(m, lr=1e-4, weight_decay=1e-5)
+    crit = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))
+    scaler = torch.amp.GradScaler("cuda")
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(n, 1, s, s, generator=g).cuda()
+    high = torch.rand(n, 1, 2 * s, 2 * s, generator=g).cuda()
+    before = m.flat_params.clone()
+    opt.zero_grad(set_to_none=True)
+    with torch.amp.autocast("cuda"):
+        assert m._resolve_dtype() == torch.float16
+        out = m(low)
+        loss = crit(out, high)
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    assert out.shape == (n, 1, 2 * s, 2 * s) and torch.isfinite(out).all()
+    assert 0.0 <= out.min().item() and out.max().item() <= 1.0
+    assert torch.isfinite(loss).item() and 0.0 < loss.item() < 2.0
+    assert torch.isfinite(m.flat_grads).all() and float(m.flat_grads.abs().max()) > 0.0
+    assert opt.step_count == 1 and scaler.get_scale() == 65536.0
+    assert torch.isfinite(m.flat_params).all() and not torch.equal(m.flat_params, before)
+    _report(f"C5 f=128 depth=5 512x512 B=8 fp16 + GradScaler: loss {loss.item():.4f}, step count {opt.step_count}, "
+            f"scale {scaler.get_scale():g}")
 
 
 def test_eval_forward_sees_optimizer_and_loaded_weights():

@@ -1,32 +1,56 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-parameter gradient error of the fp32 HIP path vs the float64 oracle at f=128, depth 5, 128x128."""
+"""Diagnostic: per-parameter gradient error of the fp32 HIP path vs the float64 oracle at f=128, depth 5, 128x128 -
+once against the oracle's OWN LeakyReLU / max-pool decisions and once with the HIP forward's decisions FORCED into the
+float64 oracle (oracle.unet_ref.unet_forward(gates=...)), which separates "two finite-precision forwards picked
+different linear pieces" from "a kernel loses precision"."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from mri_superresolution_amd.models.unet_model import UNetSuperRes
 from mri_superresolution_amd.utils.losses import CombinedLoss
 from oracle.inputs import make_pair
 from oracle.train_ref import loss_and_grads
 from oracle.unet_ref import formula_state_dict
+from hiputil import hip_gates
 
-f, depth, seed = int(os.environ.get("F", 128)), int(os.environ.get("DEPTH", 5)), 8
+f, depth, seed = int(os.environ.get("F", 128)), int(os.environ.get("DEPTH", 5)), int(os.environ.get("SEED", 8))
 S = int(os.environ.get("S", 128))
 sd = formula_state_dict(f, seed, depth=depth)
 low, high = make_pair(1, S, S, seed)
-ref_out, ref_loss, ref_grads = loss_and_grads({k: v.double() for k, v in sd.items()}, low.double(), high.double(), 0.4, depth=depth)
+sd64 = {k: v.double() for k, v in sd.items()}
+own = {}
+ref_out, ref_loss, ref_grads = loss_and_grads(sd64, low.double(), high.double(), 0.4, depth=depth, record=own)
 m = UNetSuperRes(1, 1, f, depth=depth)
 m.load_state_dict(sd)
 m = m.cuda().set_compute_dtype(torch.float32).train()
 out = m(low.cuda())
+gates = hip_gates(out, depth)
 loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(out, high.cuda())
 loss.backward()
-rows = []
-for k, p in m.named_parameters():
-    r = ref_grads[k]
-    d = (p.grad.cpu().double() - r)
-    rows.append((d.abs().max().item() / r.abs().max().item(), k, d.norm().item() / r.norm().item(),
-                 (d.abs() > 5e-4 * r.abs().max()).double().mean().item(), r.numel()))
-rows.sort(reverse=True)
-print(os.environ.get("MRISR_LIB", "default"), "loss err", abs(loss.item() - float(ref_loss)))
-for e, k, l2, frac, n in rows[:8]:
-    print(f"   max {e:.3e}  relL2 {l2:.3e}  frac>5e-4 {frac:.2e} of {n}  {k}")
+_, f_loss, f_grads = loss_and_grads(sd64, low.double(), high.double(), 0.4, depth=depth, gates=gates)
+
+
+def table(title, refg):
+    rows = []
+    for k, p in m.named_parameters():
+        r = refg[k]
+        d = (p.grad.cpu().double() - r)
+        rows.append((d.abs().max().item() / r.abs().max().item(), k, d.norm().item() / r.norm().item(),
+                     (d.abs() > 5e-4 * r.abs().max()).double().mean().item(), r.numel()))
+    rows.sort(reverse=True)
+    print(title)
+    for e, k, l2, frac, n in rows[:8]:
+        print(f"   max {e:.3e}  relL2 {l2:.3e}  frac>5e-4 {frac:.2e} of {n}  {k}")
+    print(f"   worst relL2 over all tensors {max(r[2] for r in rows):.3e}, worst max {rows[0][0]:.3e}")
+
+
+print(f"== F={f} DEPTH={depth} S={S} seed={seed}: loss err {abs(loss.item() - float(ref_loss)):.3e} "
+      f"(forced gates: {abs(loss.item() - float(f_loss)):.3e})")
+flips = [(int((gates[k] != own[k]).sum()), gates[k].numel(), k) for k in sorted(own)]
+print("decisions that differ between the HIP fp32 forward and the float64 oracle:",
+      sum(n for n, _, _ in flips), "of", sum(t for _, t, _ in flips))
+for n, t, k in sorted(flips, reverse=True)[:8]:
+    print(f"   {n:6d} of {t:9d}  {k}")
+table("-- HIP fp32 gradients vs float64 oracle, oracle's own decisions", ref_grads)
+table("-- HIP fp32 gradients vs float64 oracle with the HIP forward's decisions forced", f_grads)
