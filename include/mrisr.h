@@ -94,6 +94,9 @@ typedef struct {
                                launches that are meant to run BESIDE another stream's kernels (the weight gradients of
                                the backward pass next to the gradient chain) without either waiting for the other's CUs */
     int32_t reserved_;
+    const void* wpacked_ring; /* NULL, or the same weight in the RING layout (mrisr_pack_weights with MRISR_PACK_RING set,
+                               mrisr_packed_weight_bytes_ring > 0): mrisr_conv_forward then takes the deep-ring raw-source
+                               kernel (csrc/conv_ring.hip) where the launch qualifies, and the classic image elsewhere  */
 } mrisr_conv_desc;
 
 const char* mrisr_last_error(void);
@@ -105,8 +108,15 @@ int mrisr_stat_slots(void);
  *      flipped/transposed packed weights and a RAW source, its input-gradient. ------------- */
 /* bytes of the packed image for a (Cout,Cin,k,k) weight */
 size_t mrisr_packed_weight_bytes(int dtype, int Cout, int Cin, int ksize);
-/* w: fp32 [Cout][k][k][Cin].  transpose_flip=0: forward operand; 1: dgrad operand
- * (roles of Cin/Cout swapped, taps mirrored).                                              */
+/* w: fp32 [Cout][k][k][Cin].  transpose_flip bit 0 = 0: forward operand; 1: dgrad operand
+ * (roles of Cin/Cout swapped, taps mirrored).  | MRISR_PACK_RING: the ring layout
+ * [cout block of mrisr_conv_ring_bn()][cin chunk of 16][tap][row][32 B] read by csrc/conv_ring.hip
+ * (packed buffer of mrisr_packed_weight_bytes_ring() bytes; Cout / Cin there are the OPERAND's, i.e. already
+ * exchanged for the dgrad operand).                                                        */
+#define MRISR_PACK_RING 256
+/* output-channel block of the ring layout for an operand with these dims, 0 = the ring kernel does not take it */
+int mrisr_conv_ring_bn(int dtype, int Cout, int Cin, int ksize);
+size_t mrisr_packed_weight_bytes_ring(int dtype, int Cout, int Cin, int ksize);
 int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, int ksize, int transpose_flip,
                        void* packed, void* stream);
 /* the same for many weights in ONE launch (a training step re-packs every layer after the optimiser update):

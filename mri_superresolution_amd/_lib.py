@@ -15,6 +15,7 @@ SRC_RAW, SRC_NORM, SRC_RELU = 0, 1, 2
 SP_NONE, SP_POOL2, SP_UP2, SP_HEAD = 0, 1, 2, 3
 COMBINE_CONCAT, COMBINE_BLEND = 0, 1
 OUT_PLAIN, OUT_PIXEL_SHUFFLE2 = 0, 1
+PACK_RING = 256      # MRISR_PACK_RING: OR into transpose_flip for the ring weight layout (csrc/conv_ring.hip)
 STAT_SLOTS = 16      # = MRISR_STAT_SLOTS of include/mrisr.h; load() replaces it with the library's compiled value
 
 _vp, _fp, _dp, _i, _f, _d, _sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -32,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("combine", C.c_int32), ("out_mode", C.c_int32), ("groups", C.c_int32),
                 ("relu_out", C.c_int32), ("src", Src * 2), ("blend_alpha", _fp), ("wpacked", _vp),
                 ("bias", _fp), ("out", _vp), ("stats", _dp), ("relu_mask", _vp), ("cu_limit", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("reserved_", C.c_int32), ("wpacked_ring", _vp)]
 
 
 class PackJob(C.Structure):
@@ -68,6 +69,8 @@ SIGNATURES = {
     "mrisr_version": (_i, []),
     "mrisr_stat_slots": (_i, []),
     "mrisr_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
+    "mrisr_conv_ring_bn": (_i, [_i, _i, _i, _i]),
+    "mrisr_packed_weight_bytes_ring": (_sz, [_i, _i, _i, _i]),
     "mrisr_pack_weights": (_i, [_i, _fp, _i, _i, _i, _i, _vp, _vp]),
     "mrisr_pack_weights_batched": (_i, [_i, _vp, _i, _vp]),
     "mrisr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
@@ -113,7 +116,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 210      # mrisr_version() of the library these struct layouts and signatures belong to
+ABI_VERSION = 300      # mrisr_version() of the library these struct layouts and signatures belong to
 
 
 def load():

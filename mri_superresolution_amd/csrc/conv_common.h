@@ -49,6 +49,12 @@ static inline int conv_wgrad_fast(int dtype, int loader, int ks, int tw_log2, in
     if (!nfo || !nfi) return 0;
     return 4 / (nfo * nfi);
 }
+// output-channel block of the ring weight layout (csrc/conv_ring.hip) for an operand, 0 = that kernel does not take it
+__host__ __device__ static inline int conv_ring_bn(int dtype, int Cout, int Cin, int ksize) {
+    if (dtype != MRISR_BF16 && dtype != MRISR_F16) return 0;
+    if (ksize != 3 || Cin % 16 || Cout % 128) return 0;
+    return 128;
+}
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
 static inline int conv_bk(int dtype) { return dtype == MRISR_F32 ? 16 : 32; }
 

@@ -1186,8 +1186,30 @@ template <typename T>
 __global__ void pack_weights_batched_kernel(const PackJobDev* __restrict__ jobs) {
     constexpr int BK = kRowBytes / (int)sizeof(T);
     const PackJobDev j = jobs[blockIdx.y];
-    const int KS = j.ksize, ntaps = KS * KS, Cin = j.Cin, Cout = j.Cout, flip = j.flip;
+    const int KS = j.ksize, ntaps = KS * KS, Cin = j.Cin, Cout = j.Cout, flip = j.flip & 1;
     const int Co = flip ? Cin : Cout, Ci = flip ? Cout : Cin;   // logical (output, input) of the image
+    if (j.flip & MRISR_PACK_RING) {
+        // ring layout (conv_ring.hip): [cout block][cin chunk of 16][tap][BN rows][32 B]; the 16-B slot s of row r sits at
+        // position s ^ ((r >> 3) & 1), so that a row fragment reads conflict-free and a DMA piece is a linear copy
+        const int RBN = conv_ring_bn(TypeTraits<T>::kDtype, Co, Ci, KS);
+        if (RBN == 0) return;
+        const int rncb = Co / RBN, rnch = Ci / 16;
+        const size_t rtotal = (size_t)rncb * rnch * ntaps * RBN * 16;
+        T* __restrict__ rout = (T*)j.packed;
+        for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < rtotal; idx += (size_t)gridDim.x * blockDim.x) {
+            size_t r = idx;
+            const int e = r % 16; r /= 16;
+            const int row = r % RBN; r /= RBN;
+            const int tap = r % ntaps; r /= ntaps;
+            const int kc = r % rnch;
+            const int cb = r / rnch;
+            const int slot = (e >> 3) ^ ((row >> 3) & 1);
+            const int k = kc * 16 + slot * 8 + (e & 7), co = cb * RBN + row;
+            const float v = !flip ? j.w[((size_t)co * ntaps + tap) * Cin + k] : j.w[((size_t)k * ntaps + (ntaps - 1 - tap)) * Cin + co];
+            rout[idx] = from_f32<T>(v);
+        }
+        return;
+    }
     const int BN = Co >= 64 ? 64 : 32;                          // conv_choose_bn
     const int ncb = (Co + BN - 1) / BN, nchunks = (Ci + BK - 1) / BK;
     const size_t total = (size_t)ncb * nchunks * ntaps * BN * BK;
@@ -1240,6 +1262,20 @@ extern "C" int mrisr_pack_weights(int dtype, const float* w, int Cout, int Cin, 
                                   void* packed, void* stream) {
     if (!w || !packed) MRISR_FAIL(MRISR_E_ARG, "pack_weights: null pointer");
     if (ksize != 1 && ksize != 3) MRISR_FAIL(MRISR_E_UNSUPPORTED, "pack_weights: ksize %d", ksize);
+    if (transpose_flip & MRISR_PACK_RING) {
+        const int flip = transpose_flip & 1;
+        if (!mrisr_conv_ring_bn(dtype, flip ? Cin : Cout, flip ? Cout : Cin, ksize))
+            MRISR_FAIL(MRISR_E_UNSUPPORTED, "pack_weights: no ring layout for %d -> %d k%d dtype %d", Cin, Cout, ksize, dtype);
+        const PackJobDev job{w, packed, Cout, Cin, ksize, transpose_flip};
+        PackJobDev* dj = nullptr;      // (stand-alone packing is a test / tool path: the training step uses the batched entry)
+        if (hipMalloc(&dj, sizeof(job)) != hipSuccess) MRISR_FAIL(MRISR_E_HIP, "pack_weights: hipMalloc");
+        (void)hipMemcpyAsync(dj, &job, sizeof(job), hipMemcpyHostToDevice, (hipStream_t)stream);
+        const int rc = mrisr_pack_weights_batched(dtype, (const mrisr_pack_job*)dj, 1, stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(dj);
+        return rc;
+    }
+    transpose_flip &= 1;
     const int Co = transpose_flip ? Cin : Cout, Ci = transpose_flip ? Cout : Cin;
     const int BN = conv_choose_bn(Co), BK = conv_bk(dtype);
     const int ncb = ceil_div(Co, BN), nch = ceil_div(Ci, BK);
@@ -1328,6 +1364,9 @@ int num_cus() {
 }
 
 int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s);
+// conv_ring.hip: the deep-ring raw-source kernel
+bool conv_ring_eligible(const mrisr_conv_desc* d, const ConvParams& p);
+int launch_conv_ring(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
 
 // every source stored as-is and a plain (single / concat) loader: the halo tile can go global -> LDS by LDS-DMA
 static bool conv_dma_halo(const ConvParams& p, int spatial) {
@@ -1432,6 +1471,8 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     if (wgrad) {
         snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d,%d>", t, loader, d->ksize,
                  conv_wgrad_fast(d->dtype, loader, d->ksize, p.tw_log2, d->Cout, d->Cin));
+    } else if (conv_ring_eligible(d, p)) {
+        snprintf(out, n, "conv_ring_kernel<%s,2,4>", t);
     } else {
         const int BN = conv_choose_bn(d->Cout);
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
@@ -1452,6 +1493,7 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     if (d->relu_mask && (d->out_mode != MRISR_OUT_PLAIN || d->Cout % (mrisr_vec(d->dtype))))
         MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask needs a plain output with Cout a multiple of the 16-byte vector");
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);
+    if (conv_ring_eligible(d, p)) return launch_conv_ring(d, p, (hipStream_t)stream);
     // square 16 x 16 output tiles (324-pixel halo, 18-pixel rows) instead of 8 x 32 (340, 34): the kernels are bound by the
     // operand bytes they stage (profiles/NOTES.md R2-13/14).  32 -> 32 at 512^2: 167 -> 130 us, 64 -> 32 / 32 -> 64: 3-5 %, wide
     // layers +-2 % each, the training step -0.8 % with every 3x3 layer on 16 x 16 (A/B on one box).  The weight-gradient

@@ -197,12 +197,12 @@ class UNetEngine:
         self.timer.launch(buf.value.decode(), flops, fn)
 
     # ------------------------------------------------------------------ weights
-    def _packed_buf(self, layer: Layer, w, dt: int, flip: int):
-        key = (layer.name, dt, flip)
+    def _packed_buf(self, layer: Layer, w, dt: int, flip: int, ring: bool = False):
+        key = (layer.name, dt, flip, "ring") if ring else (layer.name, dt, flip)
         buf = self._packed.get(key)
         if buf is None or buf.device != w.device:
-            nbytes = L.load().mrisr_packed_weight_bytes(dt, layer.cin if flip else layer.cout,
-                                                        layer.cout if flip else layer.cin, layer.ks)
+            size = L.load().mrisr_packed_weight_bytes_ring if ring else L.load().mrisr_packed_weight_bytes
+            nbytes = size(dt, layer.cin if flip else layer.cout, layer.cout if flip else layer.cin, layer.ks)
             buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
             self._packed[key] = buf
         return buf
@@ -222,7 +222,7 @@ class UNetEngine:
         dev = params[self.layers[0].name + ".weight"].device
         key = (dt, str(dev), tuple(params[l.name + ".weight"].data_ptr() for l in self.layers))
         if getattr(self, "_jobs_key", None) != key:
-            jobs = (L.PackJob * (2 * len(self.layers)))()
+            jobs = (L.PackJob * (4 * len(self.layers)))()
             i = 0
             for layer in self.layers:
                 w = params[layer.name + ".weight"]
@@ -231,6 +231,14 @@ class UNetEngine:
                     j = jobs[i]
                     j.w, j.packed, j.Cout, j.Cin, j.ksize, j.transpose_flip = w.data_ptr(), buf.data_ptr(), layer.cout, layer.cin, layer.ks, flip
                     i += 1
+                    # operands the deep-ring raw-source kernel can take (csrc/conv_ring.hip) get a second image in its layout
+                    co, ci = (layer.cin, layer.cout) if flip else (layer.cout, layer.cin)
+                    if not TUNING.no_ring and L.load().mrisr_conv_ring_bn(dt, co, ci, layer.ks) > 0:
+                        buf = self._packed_buf(layer, w, dt, flip, ring=True)
+                        j = jobs[i]
+                        j.w, j.packed, j.Cout, j.Cin, j.ksize, j.transpose_flip = (w.data_ptr(), buf.data_ptr(), layer.cout, layer.cin,
+                                                                                   layer.ks, flip | L.PACK_RING)
+                        i += 1
             host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
             self._jobs_dev = host.to(dev)
             self._jobs_n = i
@@ -355,6 +363,7 @@ class UNetEngine:
             o.raw = torch.empty((N, o.H, o.W, o.C), dtype=dtype, device=dev)
             d = self._desc(layer, dt, N, params)
             d.wpacked = self._packed[(layer.name, dt, 0)].data_ptr()
+            d.wpacked_ring = L.ptr(self._packed.get((layer.name, dt, 0, "ring")))
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
             if layer.post_up:
                 zlow = torch.empty((N, vh, vw, o.C), dtype=dtype, device=dev)
@@ -555,6 +564,7 @@ class UNetEngine:
             dd.src[0].C, dd.src[0].H, dd.src[0].W = layer.cout, layer.H, layer.W
             dd.src[0].mode, dd.src[0].spatial = L.SRC_RAW, L.SP_NONE
             dd.wpacked = self._packed[(layer.name, dt, 1)].data_ptr()
+            dd.wpacked_ring = L.ptr(self._packed.get((layer.name, dt, 1, "ring")))
             dain = torch.empty((N, layer.H, layer.W, layer.cin), dtype=dtype, device=dev)
             dd.out = dain.data_ptr()
             dd.cu_limit = _CU_LIMIT

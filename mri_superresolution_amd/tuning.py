@@ -10,6 +10,8 @@ that `tools/` can A/B schedules on one box without editing the package.  libmris
   MRISR_WGRAD_LAST     1: input gradient before weight gradient inside a layer's backward step (default 0)
   MRISR_CU_LIMIT       size every persistent convolution for this many CUs (0 = whole chip)
   MRISR_SIDE_PRIO      priority of the second stream (default -1 = high: its own hardware queue class)
+  MRISR_NO_RING        1: the engine hands no ring-layout weight images over, i.e. every convolution runs the classic
+                       conv_igemm kernels (A/B of csrc/conv_ring.hip inside the training step)
   MRISR_FORCE_DP       1: bench.py / scripts wrap the model in DataParallel even at world size 1 (rehearses the RCCL path)
 """
 from __future__ import annotations
@@ -37,6 +39,7 @@ class Tuning:
     cu_limit: int
     side_prio: int
     force_dp: bool
+    no_ring: bool
 
 
 def _read() -> Tuning:
@@ -48,6 +51,7 @@ def _read() -> Tuning:
         cu_limit=_int("MRISR_CU_LIMIT", 0),
         side_prio=_int("MRISR_SIDE_PRIO", -1),
         force_dp=_int("MRISR_FORCE_DP", 0) == 1,
+        no_ring=_int("MRISR_NO_RING", 0) == 1,
     )
 
 

@@ -40,12 +40,17 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def pack(w: torch.Tensor, dt, flip=0) -> torch.Tensor:
+def pack(w: torch.Tensor, dt, flip=0, ring=False):
+    """Packed LDS image of a (Cout,Cin,k,k) weight; ring=True: the layout of csrc/conv_ring.hip (None when that kernel
+    does not take an operand of these dims)."""
     co, ci, k, _ = w.shape
-    nbytes = L.load().mrisr_packed_weight_bytes(dt, ci if flip else co, co if flip else ci, k)
+    size = L.load().mrisr_packed_weight_bytes_ring if ring else L.load().mrisr_packed_weight_bytes
+    nbytes = size(dt, ci if flip else co, co if flip else ci, k)
+    if ring and nbytes == 0:
+        return None
     buf = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     wd = w_cl(w)
-    L.call("mrisr_pack_weights", dt, wd.data_ptr(), co, ci, k, flip, buf.data_ptr(), stream())
+    L.call("mrisr_pack_weights", dt, wd.data_ptr(), co, ci, k, flip | (L.PACK_RING if ring else 0), buf.data_ptr(), stream())
     torch.cuda.synchronize()
     return buf
 
@@ -108,13 +113,18 @@ def ref_conv_input(srcs, dt, H, W, combine=L.COMBINE_CONCAT, alpha=None) -> torc
 
 
 def conv_forward(dt, srcs, w, H, W, ks, bias=None, combine=L.COMBINE_CONCAT, out_mode=L.OUT_PLAIN, alpha=None,
-                 with_stats=True):
+                 with_stats=True, use_ring=True, variant=None, cu_limit=0, relu_out=0):
+    """``use_ring``: also hand over the ring-layout image, so that launches that qualify take csrc/conv_ring.hip (as the
+    engine does); ``variant`` (optional list): receives the name of the kernel instantiation that ran."""
     keep = []
     cout, cin = w.shape[0], w.shape[1]
     d = make_desc(dt, srcs, H, W, cin, cout, ks, combine, out_mode, alpha, keep)
+    d.cu_limit, d.relu_out = cu_limit, relu_out
     N = d.N
     wp = pack(w, dt, 0)
     d.wpacked = wp.data_ptr()
+    wr = pack(w, dt, 0, ring=True) if use_ring else None
+    d.wpacked_ring = L.ptr(wr)
     if bias is not None:
         bd = bias.to(DEV)
         keep.append(bd)
@@ -127,6 +137,10 @@ def conv_forward(dt, srcs, w, H, W, ks, bias=None, combine=L.COMBINE_CONCAT, out
     stats = torch.zeros(L.STAT_SLOTS * N * 8 * 2, dtype=torch.float64, device=DEV)
     if with_stats:
         d.stats = stats.data_ptr()
+    if variant is not None:
+        name = C.create_string_buffer(96)
+        L.call("mrisr_conv_variant", C.byref(d), 0, name, 96)
+        variant.append(name.value.decode())
     L.call("mrisr_conv_forward", C.byref(d), stream())
     torch.cuda.synchronize()
     return nchw(out), stats.cpu().view(L.STAT_SLOTS, N, 8, 2).sum(0)

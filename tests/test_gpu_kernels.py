@@ -103,6 +103,46 @@ def test_conv_dma_halo_raw_sources(dt, case):
     assert name.value.decode().endswith(",1>"), name.value
 
 
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("case", ["short", "multi_tile", "padded_source", "bias_relu_nostats", "half_chip"])
+def test_conv_ring_raw_source(dt, case):
+    """csrc/conv_ring.hip (deep LDS-DMA ring, 16 x 32 x 128-channel items): launches that qualify - one stored source,
+    3x3, Cout a multiple of 128, Cin of 16, planes of whole 16 x 32 tiles, enough tiles for the chip - against the same
+    torch-CPU conv as the classic kernel.  short: one tile per workgroup; multi_tile: two
+    tiles per workgroup with an image change inside a range and GroupNorm statistics; padded_source: the source is
+    smaller than the conv input and offset inside it (out-of-source halo pixels come from the zero block);
+    bias_relu_nostats: the input-gradient / VGG form of the epilogue; half_chip: grid sized by cu_limit."""
+    n, cin, cout, h, w = {"short": (8, 256, 256, 64, 96), "multi_tile": (3, 256, 128, 256, 256),
+                          "padded_source": (8, 256, 256, 64, 96), "bias_relu_nostats": (8, 272, 256, 64, 96),
+                          "half_chip": (8, 256, 128, 64, 96)}[case]
+    hs, ws, off = (h, w, (0, 0)) if case != "padded_source" else (h - 3, w - 7, (1, 4))
+    x, wt = rnd(n, cin, hs, ws, seed=41), rnd(cout, cin, 3, 3, seed=42, scale=0.1)
+    srcs = [U.SrcSpec(x, off=off)]
+    bias = rnd(cout, seed=43) if case == "bias_relu_nostats" else None
+    ran = []
+    kw = dict(bias=bias, with_stats=case != "bias_relu_nostats", variant=ran)
+    if case == "half_chip":
+        kw["cu_limit"] = 128
+    if case == "bias_relu_nostats":
+        kw["relu_out"] = 1
+    out, stats = U.conv_forward(dt, srcs, wt, h, w, 3, **kw)
+    assert ran[0].startswith("conv_ring_kernel<"), ran
+    ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w), U.rounded(wt, dt), bias, padding=1)
+    if case == "bias_relu_nostats":
+        ref = F.relu(ref)
+    assert U.relerr(out, ref) <= TOL_OUT[dt]
+    if kw["with_stats"]:
+        o = ref.view(n, 8, cout // 8, h, w).double()
+        assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-3 * o.abs().max().item())
+        assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    # the classic kernel on the same descriptor agrees to the storage rounding (different summation order)
+    ran2 = []
+    kw["variant"] = ran2
+    out2, _ = U.conv_forward(dt, srcs, wt, h, w, 3, use_ring=False, **kw)
+    assert ran2[0].startswith("conv_igemm_kernel<"), ran2
+    assert U.relerr(out, out2) <= TOL_OUT[dt]
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv1x1_and_bias(dt):
     n, cin, cout, h, w = 2, 64, 32, 20, 36

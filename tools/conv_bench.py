@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--raw", action="store_true", help="RAW source mode instead of NORM")
     ap.add_argument("--no-ws", action="store_true", help="wgrad: float atomics instead of the two-stage reduction")
+    ap.add_argument("--no-ring", action="store_true", help="do not hand over ring-layout weights (classic kernels only)")
+    ap.add_argument("--cu-limit", type=int, default=0)
     a = ap.parse_args()
     dt = L.BF16 if a.dtype == "bf16" else L.F32
     tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
@@ -90,6 +92,17 @@ def main():
         out = torch.empty(N, H, W, cout, device=dev, dtype=tdt)
         stats = torch.zeros(L.STAT_SLOTS * N * 16, dtype=torch.float64, device=dev)
         d.wpacked, d.out, d.stats = wp.data_ptr(), out.data_ptr(), (None if a.no_stats else stats.data_ptr())
+        d.cu_limit = a.cu_limit
+        rings = []
+        if not a.no_ring and dt != L.F32:
+            for flip, (co_, ci_) in ((0, (cout, cin)), (1, (cin, cout))):
+                nb = L.load().mrisr_packed_weight_bytes_ring(dt, co_, ci_, ks)
+                r = None
+                if nb:
+                    r = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    L.call("mrisr_pack_weights", dt, w.data_ptr(), cout, cin, ks, flip | L.PACK_RING, r.data_ptr(), st)
+                rings.append(r)
+            d.wpacked_ring = L.ptr(rings[0])
         if a.raw:
             for i in range(nsrc):
                 d.src[i].mode = L.SRC_RAW
@@ -100,6 +113,9 @@ def main():
         dd.src[0].mode, dd.src[0].spatial = L.SRC_RAW, L.SP_NONE
         da = torch.empty(N, H, W, cin, device=dev, dtype=tdt)
         dd.wpacked, dd.out = wpf.data_ptr(), da.data_ptr()
+        dd.cu_limit = a.cu_limit
+        if rings:
+            dd.wpacked_ring = L.ptr(rings[1])
         dw = torch.zeros(cout, ks, ks, cin, device=dev)
         wsb = None if a.no_ws else torch.empty(max(L.load().mrisr_conv_wgrad_workspace_floats(C.byref(d)), 1), device=dev)
         flops = 2.0 * N * H * W * cin * cout * ks * ks
@@ -110,6 +126,8 @@ def main():
         line = f"{name:8s} {cin:4d}->{cout:4d} k{ks} {H:4d}^2 "
         for kind in a.kinds.split(","):
             fn = calls[kind]
+            vb = C.create_string_buffer(96)
+            L.call("mrisr_conv_variant", C.byref(dd if kind == "dgrad" else d), 1 if kind == "wgrad" else 0, vb, 96)
             fn()
             torch.cuda.synchronize()
             if hasattr(L.load(), "mrisr_debug_phase_reset"):
@@ -122,7 +140,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             tot[kind] = tot.get(kind, 0.0) + us
-            line += f"| {kind} {us:8.1f} us {flops / us / 1e6:7.1f} TF/s "
+            line += f"| {kind} {us:8.1f} us {flops / us / 1e6:7.1f} TF/s {vb.value.decode().replace('conv_', '').replace('_kernel', '')} "
             if kind != "wgrad" and hasattr(L.load(), "mrisr_debug_phase_cycles"):
                 # profiling build (tools/build_prof.sh, MRISR_LIB=...): s_memtime cycles of the middle workgroup's
                 # two halves in the last launch: load wait, commit, issue, epilogue, barrier (vector side), MFMA block,
@@ -132,7 +150,10 @@ def main():
                 names = ["ldwait", "commit", "geom", "issue", "epilog", "bar_v", "mfma", "bar_m", "loop", "flush", "-", "-"]
                 for h in range(8):
                     v = [buf[12 * h + k] // max(a.iters, 1) for k in range(10)]
+                    rt = buf[12 * h + 10] // max(a.iters, 1)      # 100 MHz ticks of the same interval -> shader clock
                     line += f"\n      wave{h} cycles total {sum(v):8d}: " + " ".join(f"{n}={x}" for n, x in zip(names, v))
+                    if rt:
+                        line += f" clock={sum(v) / rt * 0.1:.2f}GHz"
         print(line, flush=True)
     print("total us per kind:", {k: round(v, 1) for k, v in tot.items()})
 
