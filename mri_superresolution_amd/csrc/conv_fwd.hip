@@ -1366,6 +1366,7 @@ int num_cus() {
 int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int C, int groups, hipStream_t s);
 // conv_ring.hip: the deep-ring raw-source kernel
 bool conv_ring_eligible(const mrisr_conv_desc* d, const ConvParams& p);
+bool conv_wgrad_rows_ok(const mrisr_conv_desc* d);
 int launch_conv_ring(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
 
 // every source stored as-is and a plain (single / concat) loader: the halo tile can go global -> LDS by LDS-DMA
@@ -1468,7 +1469,9 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     if (!out || n < 8) MRISR_FAIL(MRISR_E_ARG, "conv_variant: bad buffer");
     const char* t = d->dtype == MRISR_BF16 ? "bf16" : (d->dtype == MRISR_F16 ? "f16" : "f32");
     const int loader = d->combine == MRISR_COMBINE_BLEND ? 3 : d->src[0].spatial;
-    if (wgrad) {
+    if (wgrad && conv_wgrad_rows_ok(d)) {
+        snprintf(out, n, "conv_wgrad_rows_kernel<%s>", t);
+    } else if (wgrad) {
         snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d,%d>", t, loader, d->ksize,
                  conv_wgrad_fast(d->dtype, loader, d->ksize, p.tw_log2, d->Cout, d->Cin));
     } else if (conv_ring_eligible(d, p)) {

@@ -463,6 +463,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #ifndef MRISR_KERNEL_ONLY
 int conv_fill_params(const mrisr_conv_desc* d, ConvParams& p, const char* who);
 int num_cus();
+// conv_wgrad_rows.hip: the row-streaming producer / consumer kernel (16-bit, 3x3, 64 x 64 channel blocks)
+bool conv_wgrad_rows_ok(const mrisr_conv_desc* d);
+size_t conv_wgrad_rows_workspace_floats(const ConvParams& p);
+int launch_wgrad_rows(int dtype, ConvParams& p, size_t ws_floats, hipStream_t s);
 
 static void wgrad_grid(const ConvParams& p, int BC, int& nblk, int& ksplit) {
     nblk = ceil_div(p.Cout, BC) * ceil_div(p.Cin, BC);
@@ -528,7 +532,10 @@ extern "C" size_t mrisr_conv_wgrad_workspace_floats(const mrisr_conv_desc* d) {
     const int BC = d->dtype == MRISR_F32 ? 32 : 64;
     int nblk, ksplit;
     wgrad_grid(p, BC, nblk, ksplit);
-    return (size_t)nblk * ksplit * 8 * ((d->ksize * d->ksize + 1) / 2) * 16 * 64;
+    const size_t classic = (size_t)nblk * ksplit * 8 * ((d->ksize * d->ksize + 1) / 2) * 16 * 64;
+    if (!conv_wgrad_rows_ok(d)) return classic;
+    const size_t rows = conv_wgrad_rows_workspace_floats(p);
+    return rows > classic ? rows : classic;
 }
 
 extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float* dw, float* workspace,
@@ -539,11 +546,13 @@ extern "C" int mrisr_conv_wgrad(const mrisr_conv_desc* d, const void* dy, float*
     if (!dy || !dw) MRISR_FAIL(MRISR_E_ARG, "conv_wgrad: null dy/dw");
     const int vec = mrisr_vec(d->dtype);
     if (d->Cout % vec) MRISR_FAIL(MRISR_E_SHAPE, "conv_wgrad: Cout %d not a multiple of %d", d->Cout, vec);
+    if ((size_t)d->N * d->H * d->W * d->Cout >= (1ull << 31)) MRISR_FAIL(MRISR_E_SHAPE, "conv_wgrad: dy exceeds 2^31 elements");
     p.dy = dy;
     p.dw = dw;
     p.wsp = workspace;
     p_ws_floats = workspace ? workspace_floats : 0;
     hipStream_t s = (hipStream_t)stream;
+    if (conv_wgrad_rows_ok(d)) return launch_wgrad_rows(d->dtype, p, p_ws_floats, s);
     if (d->dtype == MRISR_BF16) return dispatch_wgrad<bf16_t>(p, d->src[0].spatial, d->ksize, s);
     if (d->dtype == MRISR_F16) return dispatch_wgrad<f16_t>(p, d->src[0].spatial, d->ksize, s);
     return dispatch_wgrad<float>(p, d->src[0].spatial, d->ksize, s);

@@ -1,0 +1,444 @@
+// Weight gradient of the 3x3 convolution on MFMA, ROW-STREAMING form (gfx950): 16-bit storage, channel blocks of 64 x 64.
+//
+// Replaces aten convolution_backward's weight branch for the nn.Conv2d layers of /root/reference/models/unet_model.py
+// (:29,34,101,152,168), like conv_wgrad.hip, whose generic kernel keeps the 1x1 / 32-channel / fp32 / gather cases.
+//   dW[co][ky][kx][ci] += sum_pixels dy[y][x][co] * in[y + ky - 1][x + kx - 1][ci]
+//
+// What conv_wgrad_kernel<T,0,3,1> spends its time on (profiles/NOTES.md R2-12, R3-2): every wave owns ONE 32 x 32 output
+// fragment per tap, so a B fragment is read from LDS for every MFMA (1.2 KB of transposing reads per MFMA = ~60 % of the
+// LDS array at the full MFMA rate, plus 76 KB of staging writes per tile), and the same eight waves that run the MFMAs also
+// load, GroupNorm+LeakyReLU-transform and store the next tile.  Two changes:
+//   * vertical tap re-use.  A tile is 16 x 16 pixels and a k-step is ONE tile row (16 pixels).  The B fragment of halo row h
+//     and column shift kx serves the taps (ky, kx) of pixel rows h - ky, ky = 0..2, and the A fragment (dy) of pixel row y
+//     serves halo rows y .. y + 2: a wave that owns all nine taps of one (co, ci) fragment pair loads ONE new A and THREE
+//     new B fragments per halo row for NINE MFMAs - 0.44 instead of 1.2 KB of LDS reads per MFMA;
+//   * producer / consumer waves.  Waves 0-3 (one per SIMD, the older ones: they win the matrix-pipe arbitration) only read
+//     fragments and issue MFMAs - 144 accumulator registers each; waves 4-7 only stage: global loads of the tile after
+//     next into registers, GroupNorm + LeakyReLU on the tile that has arrived, LDS stores.  One barrier per tile.
+#include <mutex>
+#include <type_traits>
+
+#include "conv_common.h"
+
+// Ablation switches of tuning builds (tools/build_src_variant.sh; results invalid by construction, timing only):
+// 1 no MFMA, 2 no GroupNorm / LeakyReLU transform, 4 no global loads, 8 no LDS stores.  0 in the product library.
+#ifndef MRISR_WR_DBG
+#define MRISR_WR_DBG 0
+#endif
+// Phase profile (tuning builds only, -DMRISR_WR_PT; tools/conv_bench.py prints it): s_memtime stamps per wave of the middle
+// workgroup: slot 6 = work (MFMA block / commit + issue), slot 5 = barrier wait, slot 10 = 100 MHz ticks of the loop.
+#ifdef MRISR_WR_PT
+__device__ unsigned long long g_wr_cycles[8][12];
+#define WPT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime(); const unsigned long long pt_r0 = __builtin_amdgcn_s_memrealtime();
+#define WPT_MARK(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t; pt_t = pt_now; __builtin_amdgcn_sched_barrier(0); }
+#define WPT_DUMP() if (blockIdx.x + blockIdx.y * gridDim.x == (gridDim.x * gridDim.y) / 2 && lane == 0) { pt_acc[10] = __builtin_amdgcn_s_memrealtime() - pt_r0; for (int k = 0; k < 12; ++k) atomicAdd(&g_wr_cycles[wave][k], pt_acc[k]); if (threadIdx.x == 0) atomicAdd(&g_wr_cycles[0][11], 1ull); }
+#else
+#define WPT_DECL
+#define WPT_MARK(k)
+#define WPT_DUMP()
+#endif
+constexpr int kWrThreads = 512;
+constexpr int kWrDyBytes = 256 * 128;          // [16 x 16 px][64 co] 128-B rows
+constexpr int kWrInRows = 18 * 18;             // halo tile
+constexpr int kWrInBytes = 352 * 128;          // [18 x 18 px][64 ci] (+ 28 rows so that the last staging slot stores unpredicated)
+constexpr int kWrBuf = kWrDyBytes + kWrInBytes;
+constexpr int kWrDySlots = 8;                  // 16-B vectors per staging thread: dy 256 px x 8 chunks / 256 threads
+constexpr int kWrInSlots = 11;                 //                                halo 324 px x 8 chunks / 256 threads (last one partial)
+constexpr int kWrAcc = 9 * 16 * 64;            // accumulator floats per consumer wave (slab layout of the two-stage reduction)
+
+template <typename T>
+__device__ __forceinline__ typename Frag16<T>::type wr_tr_read(const char* base0, const char* base1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base1);
+    union { struct { s16x4 a, b; } s; typename Frag16<T>::type v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const ConvParams p_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams p = pin_params(p_in);
+    constexpr int VEC = 8;
+    typedef typename Frag16<T>::type frag_t;
+    const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool consumer = wave < 4;
+
+    const int ncib = p.Cin / 64;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-aware order (conv_wgrad.hip): the channel-block pairs of one k-slice share an L2
+        const int G = gridDim.x * gridDim.y;
+        if ((G & 7) == 0) {
+            const int id = by * gridDim.x + bx, lid = (id & 7) * (G >> 3) + (id >> 3);
+            by = lid / gridDim.x;
+            bx = lid - by * gridDim.x;
+        }
+    }
+    const int cib = bx % ncib, cob = bx / ncib;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x;
+
+    auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
+        const int tx = tile % p.tiles_x;
+        const int r = tile / p.tiles_x;
+        n = r / p.tiles_y;
+        ty0 = (r - n * p.tiles_y) * 16;
+        tx0 = tx * 16;
+    };
+
+    // ------------------------------------------------------------------ schedule: one barrier per tile
+    //   consumers:  MFMA(tile k)                                              from buffer k & 1
+    //   producers:  commit(tile k+1) into buffer (k+1) & 1  ->  issue loads(tile k+2)
+    // the operands of tile k+1 were requested a full iteration earlier and sit in the producers' registers during MFMA(k);
+    // buffer (k+1) & 1 was last read in iteration k-1, before the barrier that ended it.  The two roles are two separate
+    // loops with the same barrier sequence, so that neither role's registers are live in the other's code (one loop with a
+    // role branch keeps 144 accumulators AND 92 staging registers alive for every wave: 343 spills).
+    if (!consumer) {
+#ifdef MRISR_WR_PRIO
+        // the staging waves are the younger ones of their SIMD and lose the issue arbitration to the MFMA wave
+        __builtin_amdgcn_s_setprio(MRISR_WR_PRIO);
+#endif
+        // ------------------------------------------------------------------ producer (waves 4-7): 256 staging threads
+        // Software pipeline per SLOT: while tile k is being multiplied, slot i of tile k+1 (requested one iteration ago)
+        // is transformed and stored to LDS and the same registers immediately take the load of slot i of tile k+2 - every
+        // load has a whole iteration to arrive, whichever slot it is (with all loads issued behind the commit, the next
+        // iteration's first use waited for loads that were a barrier old: measured 26 of 95 us).
+        const int pt = t & 255, ch8 = pt & 7, rowp = pt >> 3;         // 16-B chunk of the 128-B row, first pixel row of this thread
+        Vec16<T> pdy[kWrDySlots], ph[kWrInSlots];
+        float sc[VEC], sh[VEC], scn[VEC], shn[VEC];                   // GroupNorm affine of the pending tile / of the one being loaded
+        int dymask = 0, pmask = 0, pmode = MRISR_SRC_RAW;
+        const int c_out = co0 + ch8 * VEC, c_in = ci0 + ch8 * VEC;
+        // conv input: the 64-channel block lies in ONE concat source (host-checked: src0.C is a multiple of 64)
+        const bool w1 = p.nsrc > 1 && c_in >= p.src[0].C;
+        const int cs = w1 ? c_in - p.src[0].C : c_in;
+        const T* xbase = (const T*)(w1 ? p.src[1].ptr : p.src[0].ptr);
+        const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W, Cs = w1 ? p.src[1].C : p.src[0].C;
+        const int offy = w1 ? p.src[1].off_y : p.src[0].off_y, offx = w1 ? p.src[1].off_x : p.src[0].off_x;
+        pmode = w1 ? p.src[1].mode : p.src[0].mode;
+        const float slope = pmode == MRISR_SRC_NORM ? LRELU_SLOPE : (pmode == MRISR_SRC_RELU ? 0.f : 1.f);
+
+        // Addresses: tensor base (scalar) + a 32-bit byte offset = per-tile scalar part + per-slot part that is computed
+        // ONCE (the staging waves' vector instructions run ~2.4x slower beside the other wave's MFMAs, and the address
+        // and validity arithmetic of 19 slots was as much work as the GroupNorm transform itself).  Validity masks are
+        // recomputed only for tiles that touch the plane's edge (a scalar branch without loads inside).
+        unsigned rel_dy[kWrDySlots], rel_x[kWrInSlots];
+        int st_mask_x = 0;                               // slots whose halo pixel exists (hp < 324): the last slot is partial
+    #pragma unroll
+        for (int i = 0; i < kWrDySlots; ++i) {
+            const int px = rowp + 32 * i;
+            rel_dy[i] = (unsigned)(((px >> 4) * p.W + (px & 15)) * p.Cout + c_out) * 2u;
+        }
+    #pragma unroll
+        for (int i = 0; i < kWrInSlots; ++i) {
+            const int hp = rowp + 32 * i;
+            const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18 for hp < 352
+            rel_x[i] = (unsigned)((hy * Ws + hx) * Cs + cs) * 2u;
+            st_mask_x |= (hp < kWrInRows ? 1 : 0) << i;
+        }
+        auto load_dy = [&](int i, unsigned tile_off, int mask) {
+            if (MRISR_WR_DBG & 4) return;
+            const unsigned off = ((mask >> i) & 1) ? tile_off + rel_dy[i] : 0u;
+            pdy[i] = gload_vec16(reinterpret_cast<const T*>((const char*)p.dy + off));
+        };
+        auto load_x = [&](int i, unsigned tile_off, int mask) {
+            if (MRISR_WR_DBG & 4) return;
+            const unsigned off = ((mask >> i) & 1) ? tile_off + rel_x[i] : 0u;
+            ph[i] = gload_vec16(reinterpret_cast<const T*>((const char*)xbase + off));
+        };
+        // validity of this thread's slots for the tile at (ty0, tx0): bit i of the two masks
+        auto tile_masks = [&](int ty0, int tx0, int& dm, int& pm) {
+            const int ys0 = ty0 - 1 - offy, xs0 = tx0 - 1 - offx;
+            const bool interior = ty0 + 16 <= p.H && tx0 + 16 <= p.W && ys0 >= 0 && xs0 >= 0 && ys0 + 18 <= Hs && xs0 + 18 <= Ws;
+            dm = (1 << kWrDySlots) - 1;
+            pm = st_mask_x;
+            if (!interior) {
+                int rq = rowp;
+                asm volatile("" : "+v"(rq));
+                dm = 0;
+                pm = 0;
+    #pragma unroll
+                for (int i = 0; i < kWrDySlots; ++i) {
+                    const int px = rq + 32 * i;
+                    dm |= ((ty0 + (px >> 4) < p.H && tx0 + (px & 15) < p.W) ? 1 : 0) << i;
+                }
+    #pragma unroll
+                for (int i = 0; i < kWrInSlots; ++i) {
+                    const int hp = rq + 32 * i;
+                    const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
+                    const unsigned y = ys0 + hy, x = xs0 + hx;
+                    pm |= ((hp < kWrInRows && y < (unsigned)Hs && x < (unsigned)Ws) ? 1 : 0) << i;
+                }
+            }
+        };
+        auto dy_tile_off = [&](int n, int ty0, int tx0) { return (unsigned)(((n * p.H + ty0) * p.W + tx0) * p.Cout) * 2u; };
+        auto x_tile_off = [&](int n, int ty0, int tx0) {      // (may be "negative": the sum with a valid slot's part is not)
+            return (unsigned)(((n * Hs + ty0 - 1 - offy) * Ws + tx0 - 1 - offx) * Cs) * 2u;
+        };
+        auto load_aff = [&](int n) {
+            if (w1) load_affine<VEC>(p.src[1], n, cs, scn, shn);
+            else load_affine<VEC>(p.src[0], n, cs, scn, shn);
+        };
+        // stores the pending tile (registers) into `buf` and refills every slot with tile (n, ty0, tx0).  STRAIGHT-LINE on
+        // purpose: no branch inside (the tail re-loads the last tile and stores a tile nobody reads) - with branches around
+        // the loads hipcc gives up counting and waits `vmcnt(0)` / `vmcnt(1)` before EVERY slot, i.e. for the load it has
+        // just issued.
+        // (sources stored as-is run the same arithmetic with scale 1, shift 0, slope 1: exact for 16-bit values)
+        auto commit_issue = [&](char* buf, int n, int ty0, int tx0) {
+            char* lds_dy = buf;
+            char* lds_in = buf + kWrDyBytes;
+            int rq = rowp;
+            asm volatile("" : "+v"(rq));
+            int dmn, pmn;
+            tile_masks(ty0, tx0, dmn, pmn);
+            const unsigned dyo = dy_tile_off(n, ty0, tx0), xo = x_tile_off(n, ty0, tx0);
+    #pragma unroll
+            for (int e = 0; e < VEC; ++e) { sc[e] = scn[e]; sh[e] = shn[e]; }
+    #pragma unroll
+            for (int i = 0; i < kWrDySlots; ++i) {
+                Vec16<T> v = pdy[i], z;
+                z.zero();
+                if (!((dymask >> i) & 1)) v = z;
+                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(v.v)*>(lds_dy + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = v.v;
+                else asm volatile("" ::"v"(v.v));
+                load_dy(i, dyo, dmn);
+            }
+    #pragma unroll
+            for (int i = 0; i < kWrInSlots; ++i) {
+                Vec16<T> v = ph[i], z;
+                z.zero();
+                if (!(MRISR_WR_DBG & 2)) {
+    #pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float y = fmaf(v.get(e), sc[e], sh[e]);
+                        v.set(e, fmaxf(y, slope * y));
+                    }
+                }
+                if (!((pmask >> i) & 1)) v = z;
+                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = v.v;
+                else asm volatile("" ::"v"(v.v));
+                load_x(i, xo, pmn);
+            }
+            load_aff(n);
+            dymask = dmn;
+            pmask = pmn;
+        };
+
+        const int last_tile = total_tiles > by ? by + ((total_tiles - 1 - by) / (int)gridDim.y) * (int)gridDim.y : by;   // this workgroup's last tile
+        int tile = by, cur = 0;
+        int n = 0, ty0 = 0, tx0 = 0;
+        if (tile < total_tiles) {
+            decode(tile, n, ty0, tx0);
+            tile_masks(ty0, tx0, dymask, pmask);
+            const unsigned dyo = dy_tile_off(n, ty0, tx0), xo = x_tile_off(n, ty0, tx0);
+    #pragma unroll
+            for (int i = 0; i < kWrDySlots; ++i) load_dy(i, dyo, dymask);
+    #pragma unroll
+            for (int i = 0; i < kWrInSlots; ++i) load_x(i, xo, pmask);
+            load_aff(n);
+            decode(min(tile + (int)gridDim.y, last_tile), n, ty0, tx0);
+            commit_issue(smem, n, ty0, tx0);
+        }
+        __syncthreads();
+        WPT_DECL
+        while (tile < total_tiles) {
+            const int nxt = tile + gridDim.y;
+            // registers hold tile nxt (or, behind the last tile, a re-load of it that lands in the buffer nobody reads)
+            decode(min(nxt + (int)gridDim.y, last_tile), n, ty0, tx0);
+            commit_issue(smem + (cur ^ 1) * kWrBuf, n, ty0, tx0);
+            WPT_MARK(6)
+            __syncthreads();
+            WPT_MARK(5)
+            cur ^= 1;
+            tile = nxt;
+        }
+        WPT_DUMP()
+        return;
+    }
+
+    // ------------------------------------------------------------------ consumer state (waves 0-3): fragment pair (fo, fi)
+    const int fo = (wave >> 1) & 1, fi = wave & 1;
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // per-lane fragment addresses of the transposing reads (layout lds_off128, as conv_wgrad.hip's fast path):
+    //   A (dy, pixel row y of the tile): a_lane + y * 2048 (second read + 512 = 4 pixels on)
+    //   B (halo pixel K .. K + 15, K = h * 18 + kx): b_lane[K & 3] + K * 128
+    int a_lane, b_lane[4];
+    {
+        const int li = lane & 15, gq = li >> 2, gp = li & 3, gr = (lane >> 4) & 1;
+        const int chb = 16 * gr + 4 * gp;
+        const int lp = 8 * lh + gq;
+        const int cbits = (((chb >> 3) & 3) << 4) + ((chb & 4) << 1);
+        a_lane = lp * 128 + ((fo ^ ((gq >> 1) & 1)) << 6) + cbits;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_lane[kk] = kWrDyBytes + lp * 128 + ((fi ^ (((kk + gq) >> 1) & 1)) << 6) + cbits;
+    }
+    // ------------------------------------------------------------------ the MFMA block of one tile (consumer waves)
+    auto mfma_tile = [&](const char* bufp) {
+        const char* ab = bufp + a_lane;
+        const char* bb[4] = {bufp + b_lane[0], bufp + b_lane[1], bufp + b_lane[2], bufp + b_lane[3]};
+        auto load_a = [&](int y) { return wr_tr_read<T>(ab + y * 2048, ab + y * 2048 + 512); };
+        auto load_b = [&](int h, int kx) {
+            const int K = h * 18 + kx;
+            const char* b = bb[K & 3] + K * 128;
+            return wr_tr_read<T>(b, b + 512);
+        };
+        // A: ring of four pixel rows (row y is used by halo rows y .. y + 2 while row y + 1 ... y + 3 arrive), B: two sets of
+        // three column shifts; everything for halo row h + 1 is requested before the MFMAs of halo row h are issued
+        frag_t A[4], B[2][3];
+        A[0] = load_a(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) B[0][kx] = load_b(0, kx);
+#pragma unroll
+        for (int h = 0; h < 18; ++h) {
+            if (h + 1 < 18) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) B[(h + 1) & 1][kx] = load_b(h + 1, kx);
+                if (h + 1 < 16) A[(h + 1) & 3] = load_a(h + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int y = h - ky;
+                if (y >= 0 && y < 16) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (MRISR_WR_DBG & 1) asm volatile("" ::"v"(A[y & 3]), "v"(B[h & 1][kx]));
+                        else acc[ky * 3 + kx] = Frag16<T>::mma(A[y & 3], B[h & 1][kx], acc[ky * 3 + kx]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        int tile = by, cur = 0;
+        __syncthreads();
+        WPT_DECL
+        while (tile < total_tiles) {
+            mfma_tile(smem + cur * kWrBuf);
+            WPT_MARK(6)
+            __syncthreads();
+            WPT_MARK(5)
+            cur ^= 1;
+            tile += gridDim.y;
+        }
+        WPT_DUMP()
+    }
+
+    // ---- two-stage reduction: the accumulators as they stand into this workgroup's slab (lane-contiguous 256-B stores)
+    if (p.wsp) {
+        float* wsb = p.wsp + ((size_t)(by * gridDim.x + bx) * 4 + wave) * kWrAcc + lane;
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gstore(wsb + (a * 16 + r) * 64, acc[a][r]);
+        return;
+    }
+    // ---- or float atomics straight into dW[co][tap][ci]: lane = ci, registers = co
+    const int ci = ci0 + fi * 32 + lr;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            atomic_add_f32(p.dw + ((size_t)co * 9 + a) * p.Cin + ci, acc[a][r]);
+        }
+}
+
+// Second stage: dw[co][tap][ci] += sum over the split-K slabs (thread = one accumulator element of the slab layout)
+constexpr int kWrRedChunk = 8;
+__global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
+                                                                int ksplit, int Cout, int Cin) {
+    const int per_blk = 4 * kWrAcc;
+    const size_t total = (size_t)nblk * per_blk;
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float s = 0.f;
+    const int k0 = blockIdx.y * kWrRedChunk;
+#pragma unroll
+    for (int k = 0; k < kWrRedChunk; ++k)
+        if (k0 + k < ksplit) s += ws[(size_t)(k0 + k) * total + idx];
+    const int blk = idx / per_blk, rem = idx - (size_t)blk * per_blk;
+    const int wave = rem / kWrAcc, ar = (rem - wave * kWrAcc) >> 6, lane = rem & 63;
+    const int a = ar >> 4, r = ar & 15, lr = lane & 31, lh = lane >> 5;
+    const int ncib = Cin / 64, cib = blk % ncib, cob = blk / ncib;
+    const int fo = (wave >> 1) & 1, fi = wave & 1;
+    const int co = cob * 64 + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ci = cib * 64 + fi * 32 + lr;
+    if (s != 0.f) atomic_add_f32(dw + ((size_t)co * 9 + a) * Cin + ci, s);
+}
+
+#ifndef MRISR_KERNEL_ONLY
+int num_cus();
+#ifdef MRISR_WR_PT
+extern "C" int mrisr_debug_phase_reset() {
+    static unsigned long long zeros[96];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wr_cycles), zeros, sizeof(zeros));
+}
+extern "C" int mrisr_debug_phase_cycles(unsigned long long* out96) {
+    return (int)hipMemcpyFromSymbol(out96, HIP_SYMBOL(g_wr_cycles), sizeof(unsigned long long) * 96);
+}
+#endif
+
+// does mrisr_conv_wgrad take the row-streaming kernel for this descriptor?
+bool conv_wgrad_rows_ok(const mrisr_conv_desc* d) {
+#ifdef MRISR_NO_WGRAD_ROWS
+    return false;
+#endif
+    if (d->dtype != MRISR_BF16 && d->dtype != MRISR_F16) return false;
+    if (d->ksize != 3 || d->combine != MRISR_COMBINE_CONCAT) return false;
+    if (d->Cout % 64 || d->Cin % 64 || d->H < 16 || d->W < 16) return false;
+    for (int s = 0; s < d->nsrc; ++s)
+        if (d->src[s].spatial != MRISR_SP_NONE) return false;
+    if (d->nsrc > 1 && d->src[0].C % 64) return false;
+    return true;
+}
+
+static void wgrad_rows_grid(const ConvParams& p, int& nblk, int& ksplit, int& total_tiles) {
+    nblk = (p.Cout / 64) * (p.Cin / 64);
+    total_tiles = p.N * ceil_div(p.H, 16) * ceil_div(p.W, 16);
+    ksplit = ceil_div(p.cus > 0 ? p.cus : num_cus(), nblk);
+    if (ksplit > total_tiles) ksplit = total_tiles;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 65535) ksplit = 65535;
+}
+
+size_t conv_wgrad_rows_workspace_floats(const ConvParams& p) {
+    int nblk, ksplit, tt;
+    wgrad_rows_grid(p, nblk, ksplit, tt);
+    return (size_t)nblk * ksplit * 4 * kWrAcc;
+}
+
+template <typename T>
+static int launch_wgrad_rows_t(ConvParams& p, size_t ws_floats, hipStream_t s) {
+    p.th = 16; p.tw_log2 = 4;
+    p.tiles_x = ceil_div(p.W, 16); p.tiles_y = ceil_div(p.H, 16);
+    int nblk, ksplit, tt;
+    wgrad_rows_grid(p, nblk, ksplit, tt);
+    const size_t need = (size_t)nblk * ksplit * 4 * kWrAcc;
+    if (!(p.wsp && ksplit >= 4 && need <= ws_floats)) p.wsp = nullptr;
+    const size_t lds = 2 * (size_t)kWrBuf;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<T>), dim3(nblk, ksplit), dim3(kWrThreads), lds, s, p);
+    MRISR_CHECK_LAUNCH("conv_wgrad(rows)");
+    if (p.wsp) {
+        const size_t total = need / ksplit;
+        wgrad_rows_reduce_kernel<<<dim3((unsigned)((total + 255) / 256), ceil_div(ksplit, kWrRedChunk)), 256, 0, s>>>(p.wsp, p.dw, nblk, ksplit, p.Cout, p.Cin);
+        MRISR_CHECK_LAUNCH("conv_wgrad(rows reduce)");
+    }
+    return MRISR_OK;
+}
+
+int launch_wgrad_rows(int dtype, ConvParams& p, size_t ws_floats, hipStream_t s) {
+    if (dtype == MRISR_BF16) return launch_wgrad_rows_t<bf16_t>(p, ws_floats, s);
+    return launch_wgrad_rows_t<f16_t>(p, ws_floats, s);
+}
+#endif

@@ -146,9 +146,13 @@ def conv_forward(dt, srcs, w, H, W, ks, bias=None, combine=L.COMBINE_CONCAT, out
     return nchw(out), stats.cpu().view(L.STAT_SLOTS, N, 8, 2).sum(0)
 
 
-def conv_wgrad(dt, srcs, dy_nchw, cout, cin, H, W, ks, combine=L.COMBINE_CONCAT, alpha=None, use_ws=False):
+def conv_wgrad(dt, srcs, dy_nchw, cout, cin, H, W, ks, combine=L.COMBINE_CONCAT, alpha=None, use_ws=False, variant=None):
     keep = []
     d = make_desc(dt, srcs, H, W, cin, cout, ks, combine, L.OUT_PLAIN, alpha, keep)
+    if variant is not None:
+        name = C.create_string_buffer(96)
+        L.call("mrisr_conv_variant", C.byref(d), 1, name, 96)
+        variant.append(name.value.decode())
     dyd = nhwc(dy_nchw, dt)
     dw = torch.zeros((cout, ks, ks, cin), dtype=torch.float32, device=DEV)
     # use_ws: two-stage (workspace) split-K reduction; otherwise float atomics straight into dw

@@ -254,6 +254,38 @@ def test_conv_wgrad(dt, case, use_ws):
 
 
 # ------------------------------------------------------------------------------------------- stem / head
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("case", ["norm_edges", "raw_wide", "concat_pad", "deep_small"])
+def test_conv_wgrad_rows(dt, case, use_ws):
+    """csrc/conv_wgrad_rows.hip (row-streaming weight gradient with producer / consumer waves): 16-bit, 3x3, Cout and Cin
+    multiples of 64, planes >= 16 x 16.  norm_edges: GroupNorm source, plane sizes that are no multiples of the 16 x 16
+    tile, several tiles per workgroup; raw_wide: a stored source, 2 x 1 channel blocks; concat_pad: two GroupNorm sources
+    of 64 channels each, the second smaller than the conv input and offset (unet_model.py:86-93); deep_small: 256 -> 128
+    channels on 16 x 16 planes (one tile per image, 8 channel-block pairs)."""
+    if case == "norm_edges":
+        n, cin, cout, h, w = 3, 64, 128, 40, 72
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=70), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 71))]
+    elif case == "raw_wide":
+        n, cin, cout, h, w = 2, 128, 64, 32, 48
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=72))]
+    elif case == "concat_pad":
+        n, cin, cout, h, w = 2, 128, 64, 33, 35
+        srcs = [U.SrcSpec(rnd(n, 64, h, w, seed=73), L.SRC_NORM, L.SP_NONE, *gn_affine(n, 64, 74)),
+                U.SrcSpec(rnd(n, 64, 32, 33, seed=75), L.SRC_NORM, L.SP_NONE, *gn_affine(n, 64, 76), off=(0, 1))]
+    else:
+        n, cin, cout, h, w = 4, 256, 128, 16, 16
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=77), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 78))]
+    dy = rnd(n, cout, h, w, seed=79)
+    ran = []
+    dw = U.conv_wgrad(dt, srcs, dy, cout, cin, h, w, 3, use_ws=use_ws, variant=ran)
+    assert ran[0].startswith("conv_wgrad_rows_kernel<"), ran
+    xin = U.ref_conv_input(srcs, dt, h, w).requires_grad_(False)
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(xin, wt, padding=1).backward(U.rounded(dy, dt))
+    assert U.relerr(dw, wt.grad) <= TOL_F32[dt]
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_stem_forward_and_wgrad(dt):
     n, cout, h, w = 2, 32, 19, 45

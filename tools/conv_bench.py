@@ -141,7 +141,7 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / a.iters
             tot[kind] = tot.get(kind, 0.0) + us
             line += f"| {kind} {us:8.1f} us {flops / us / 1e6:7.1f} TF/s {vb.value.decode().replace('conv_', '').replace('_kernel', '')} "
-            if kind != "wgrad" and hasattr(L.load(), "mrisr_debug_phase_cycles"):
+            if hasattr(L.load(), "mrisr_debug_phase_cycles"):
                 # profiling build (tools/build_prof.sh, MRISR_LIB=...): s_memtime cycles of the middle workgroup's
                 # two halves in the last launch: load wait, commit, issue, epilogue, barrier (vector side), MFMA block,
                 # barrier (matrix side), loop overhead
