@@ -107,25 +107,34 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         // load has a whole iteration to arrive, whichever slot it is (with all loads issued behind the commit, the next
         // iteration's first use waited for loads that were a barrier old: measured 26 of 95 us).
         const int pt = t & 255, ch8 = pt & 7, rowp = pt >> 3;         // 16-B chunk of the 128-B row, first pixel row of this thread
-        Vec16<T> pdy[kWrDySlots], ph[kWrInSlots];
-        float sc[VEC], sh[VEC], scn[VEC], shn[VEC];                   // GroupNorm affine of the pending tile / of the one being loaded
-        int dymask = 0, pmask = 0, pmode = MRISR_SRC_RAW;
+        // TWO register sets, two tiles ahead: a tile's loads are issued two iterations (~8 us) before its commit.  With one
+        // set (one tile = 76 KB per CU in flight) the commit waited for its data every iteration - 19.5 MB in flight
+        // chip-wide is ~4 us at the rate the memory system delivers this pattern, longer than a tile's MFMA time.
+        struct StageSet {
+            Vec16<T> dy[kWrDySlots], x[kWrInSlots];
+            float sc[VEC], sh[VEC];        // GroupNorm affine of the tile's image (this thread's 8 channels)
+            int ty0, tx0;                  // where the tile lies (edge handling at commit time)
+        };
+        StageSet S0, S1;
         const int c_out = co0 + ch8 * VEC, c_in = ci0 + ch8 * VEC;
-        // conv input: the 64-channel block lies in ONE concat source (host-checked: src0.C is a multiple of 64)
-        const bool w1 = p.nsrc > 1 && c_in >= p.src[0].C;
+        // conv input: the 64-channel block lies in ONE concat source (host-checked: src0.C is a multiple of 64) - workgroup-uniform
+        const bool w1 = __builtin_amdgcn_readfirstlane((p.nsrc > 1 && ci0 >= p.src[0].C) ? 1 : 0) != 0;
         const int cs = w1 ? c_in - p.src[0].C : c_in;
-        const T* xbase = (const T*)(w1 ? p.src[1].ptr : p.src[0].ptr);
         const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W, Cs = w1 ? p.src[1].C : p.src[0].C;
         const int offy = w1 ? p.src[1].off_y : p.src[0].off_y, offx = w1 ? p.src[1].off_x : p.src[0].off_x;
-        pmode = w1 ? p.src[1].mode : p.src[0].mode;
+        const int pmode = w1 ? p.src[1].mode : p.src[0].mode;
         const float slope = pmode == MRISR_SRC_NORM ? LRELU_SLOPE : (pmode == MRISR_SRC_RELU ? 0.f : 1.f);
-
-        // Addresses: tensor base (scalar) + a 32-bit byte offset = per-tile scalar part + per-slot part that is computed
-        // ONCE (the staging waves' vector instructions run ~2.4x slower beside the other wave's MFMAs, and the address
-        // and validity arithmetic of 19 slots was as much work as the GroupNorm transform itself).  Validity masks are
-        // recomputed only for tiles that touch the plane's edge (a scalar branch without loads inside).
+        // Loads are BUFFER loads over the whole tensor: offset = per-tile scalar part + per-slot part computed ONCE, one vector
+        // add per load and no validity arithmetic in the common path (the staging waves' vector instructions run ~2.4x slower
+        // beside the other wave's MFMAs, and addresses + masks + zero selects of 19 slots were as much work as the GroupNorm
+        // transform itself).  An offset outside the tensor returns zeros (hardware range check); halo pixels beside the plane
+        // alias into neighbouring rows - tiles that touch the plane's edge overwrite their invalid slots with zeros in a
+        // second pass (a scalar branch with LDS stores only: no load inside a branch, see commit_issue).
+        const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.dy), 0, (int)((unsigned)p.N * p.H * p.W * p.Cout * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(w1 ? p.src[1].ptr : p.src[0].ptr), 0, (int)((unsigned)p.N * Hs * Ws * Cs * 2u), 0x00020000);
         unsigned rel_dy[kWrDySlots], rel_x[kWrInSlots];
-        int st_mask_x = 0;                               // slots whose halo pixel exists (hp < 324): the last slot is partial
     #pragma unroll
         for (int i = 0; i < kWrDySlots; ++i) {
             const int px = rowp + 32 * i;
@@ -136,79 +145,58 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
             const int hp = rowp + 32 * i;
             const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18 for hp < 352
             rel_x[i] = (unsigned)((hy * Ws + hx) * Cs + cs) * 2u;
-            st_mask_x |= (hp < kWrInRows ? 1 : 0) << i;
         }
-        auto load_dy = [&](int i, unsigned tile_off, int mask) {
-            if (MRISR_WR_DBG & 4) return;
-            const unsigned off = ((mask >> i) & 1) ? tile_off + rel_dy[i] : 0u;
-            pdy[i] = gload_vec16(reinterpret_cast<const T*>((const char*)p.dy + off));
-        };
-        auto load_x = [&](int i, unsigned tile_off, int mask) {
-            if (MRISR_WR_DBG & 4) return;
-            const unsigned off = ((mask >> i) & 1) ? tile_off + rel_x[i] : 0u;
-            ph[i] = gload_vec16(reinterpret_cast<const T*>((const char*)xbase + off));
-        };
-        // validity of this thread's slots for the tile at (ty0, tx0): bit i of the two masks
-        auto tile_masks = [&](int ty0, int tx0, int& dm, int& pm) {
-            const int ys0 = ty0 - 1 - offy, xs0 = tx0 - 1 - offx;
-            const bool interior = ty0 + 16 <= p.H && tx0 + 16 <= p.W && ys0 >= 0 && xs0 >= 0 && ys0 + 18 <= Hs && xs0 + 18 <= Ws;
-            dm = (1 << kWrDySlots) - 1;
-            pm = st_mask_x;
-            if (!interior) {
-                int rq = rowp;
-                asm volatile("" : "+v"(rq));
-                dm = 0;
-                pm = 0;
-    #pragma unroll
-                for (int i = 0; i < kWrDySlots; ++i) {
-                    const int px = rq + 32 * i;
-                    dm |= ((ty0 + (px >> 4) < p.H && tx0 + (px & 15) < p.W) ? 1 : 0) << i;
-                }
-    #pragma unroll
-                for (int i = 0; i < kWrInSlots; ++i) {
-                    const int hp = rq + 32 * i;
-                    const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
-                    const unsigned y = ys0 + hy, x = xs0 + hx;
-                    pm |= ((hp < kWrInRows && y < (unsigned)Hs && x < (unsigned)Ws) ? 1 : 0) << i;
-                }
-            }
-        };
         auto dy_tile_off = [&](int n, int ty0, int tx0) { return (unsigned)(((n * p.H + ty0) * p.W + tx0) * p.Cout) * 2u; };
         auto x_tile_off = [&](int n, int ty0, int tx0) {      // (may be "negative": the sum with a valid slot's part is not)
             return (unsigned)(((n * Hs + ty0 - 1 - offy) * Ws + tx0 - 1 - offx) * Cs) * 2u;
         };
-        auto load_aff = [&](int n) {
-            if (w1) load_affine<VEC>(p.src[1], n, cs, scn, shn);
-            else load_affine<VEC>(p.src[0], n, cs, scn, shn);
+        auto load_slot_dy = [&](StageSet& S, int i, unsigned tile_off) {
+            if (MRISR_WR_DBG & 4) return;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, (int)(tile_off + rel_dy[i]), 0, 0);
+            S.dy[i].v = __builtin_bit_cast(decltype(S.dy[i].v), r);
         };
-        // stores the pending tile (registers) into `buf` and refills every slot with tile (n, ty0, tx0).  STRAIGHT-LINE on
-        // purpose: no branch inside (the tail re-loads the last tile and stores a tile nobody reads) - with branches around
-        // the loads hipcc gives up counting and waits `vmcnt(0)` / `vmcnt(1)` before EVERY slot, i.e. for the load it has
-        // just issued.
+        auto load_slot_x = [&](StageSet& S, int i, unsigned tile_off) {
+            if (MRISR_WR_DBG & 4) return;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(tile_off + rel_x[i]), 0, 0);
+            S.x[i].v = __builtin_bit_cast(decltype(S.x[i].v), r);
+        };
+        auto load_aff = [&](StageSet& S, int n) {
+            if (w1) load_affine<VEC>(p.src[1], n, cs, S.sc, S.sh);
+            else load_affine<VEC>(p.src[0], n, cs, S.sc, S.sh);
+        };
+        auto load_all = [&](StageSet& S, int n, int ty0, int tx0) {
+            const unsigned dyo = dy_tile_off(n, ty0, tx0), xo = x_tile_off(n, ty0, tx0);
+    #pragma unroll
+            for (int i = 0; i < kWrDySlots; ++i) load_slot_dy(S, i, dyo);
+    #pragma unroll
+            for (int i = 0; i < kWrInSlots; ++i) load_slot_x(S, i, xo);
+            load_aff(S, n);
+            S.ty0 = ty0; S.tx0 = tx0;
+        };
+        // Stores the tile held by set S into `buf` and refills every slot of S with tile (n, ty0, tx0).  STRAIGHT-LINE on
+        // purpose: no branch around a load (the tail re-loads the last tile and stores a tile nobody reads) - with branches
+        // around the loads hipcc gives up counting and waits `vmcnt(0)` / `vmcnt(1)` before EVERY slot, i.e. for the load it
+        // has just issued.
         // (sources stored as-is run the same arithmetic with scale 1, shift 0, slope 1: exact for 16-bit values)
-        auto commit_issue = [&](char* buf, int n, int ty0, int tx0) {
+        auto commit_issue = [&](StageSet& S, char* buf, int n, int ty0, int tx0) {
             char* lds_dy = buf;
             char* lds_in = buf + kWrDyBytes;
             int rq = rowp;
             asm volatile("" : "+v"(rq));
-            int dmn, pmn;
-            tile_masks(ty0, tx0, dmn, pmn);
             const unsigned dyo = dy_tile_off(n, ty0, tx0), xo = x_tile_off(n, ty0, tx0);
+            const int pty0 = S.ty0, ptx0 = S.tx0;
+            float sc[VEC], sh[VEC];
     #pragma unroll
-            for (int e = 0; e < VEC; ++e) { sc[e] = scn[e]; sh[e] = shn[e]; }
+            for (int e = 0; e < VEC; ++e) { sc[e] = S.sc[e]; sh[e] = S.sh[e]; }
     #pragma unroll
             for (int i = 0; i < kWrDySlots; ++i) {
-                Vec16<T> v = pdy[i], z;
-                z.zero();
-                if (!((dymask >> i) & 1)) v = z;
-                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(v.v)*>(lds_dy + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = v.v;
-                else asm volatile("" ::"v"(v.v));
-                load_dy(i, dyo, dmn);
+                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(S.dy[i].v)*>(lds_dy + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = S.dy[i].v;
+                else asm volatile("" ::"v"(S.dy[i].v));
+                load_slot_dy(S, i, dyo);
             }
     #pragma unroll
             for (int i = 0; i < kWrInSlots; ++i) {
-                Vec16<T> v = ph[i], z;
-                z.zero();
+                Vec16<T> v = S.x[i];
                 if (!(MRISR_WR_DBG & 2)) {
     #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
@@ -216,43 +204,71 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
                         v.set(e, fmaxf(y, slope * y));
                     }
                 }
-                if (!((pmask >> i) & 1)) v = z;
                 if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = v.v;
                 else asm volatile("" ::"v"(v.v));
-                load_x(i, xo, pmn);
+                load_slot_x(S, i, xo);
             }
-            load_aff(n);
-            dymask = dmn;
-            pmask = pmn;
+            load_aff(S, n);
+            S.ty0 = ty0; S.tx0 = tx0;
+            // edge tiles: zeros over the slots that lie outside the plane / the source (conv padding, partial tiles)
+            const int ys0 = pty0 - 1 - offy, xs0 = ptx0 - 1 - offx;
+            const bool interior = pty0 + 16 <= p.H && ptx0 + 16 <= p.W && ys0 >= 0 && xs0 >= 0 && ys0 + 18 <= Hs && xs0 + 18 <= Ws;
+            if (!interior) {
+                Vec16<T> z;
+                z.zero();
+    #pragma unroll
+                for (int i = 0; i < kWrDySlots; ++i) {
+                    const int px = rq + 32 * i;
+                    if (!(pty0 + (px >> 4) < p.H && ptx0 + (px & 15) < p.W))
+                        *reinterpret_cast<decltype(z.v)*>(lds_dy + lds_off128(px, ch8 >> 2, ch8 & 3)) = z.v;
+                }
+    #pragma unroll
+                for (int i = 0; i < kWrInSlots; ++i) {
+                    const int hp = rq + 32 * i;
+                    const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
+                    const unsigned y = ys0 + hy, x = xs0 + hx;
+                    if (!(y < (unsigned)Hs && x < (unsigned)Ws))      // (rows 324 .. 351 of the last slot are never read)
+                        *reinterpret_cast<decltype(z.v)*>(lds_in + lds_off128(hp, ch8 >> 2, ch8 & 3)) = z.v;
+                }
+            }
         };
 
         const int last_tile = total_tiles > by ? by + ((total_tiles - 1 - by) / (int)gridDim.y) * (int)gridDim.y : by;   // this workgroup's last tile
+        // schedule (G = gridDim.y, tile sequence t0 = by, t1 = t0 + G, ...; indices beyond the last tile re-load the last tile):
+        //   prologue: S0 <- t0, S1 <- t1; commit S0 -> buffer 0 and S0 <- t2; barrier
+        //   iteration k (consumers multiply t_k from buffer k & 1): commit S[(k+1) & 1] = t_{k+1} -> buffer (k+1) & 1, refill <- t_{k+3}
+        const int G = (int)gridDim.y;
         int tile = by, cur = 0;
         int n = 0, ty0 = 0, tx0 = 0;
+        auto tile_at = [&](int idx) { return min(idx, last_tile); };
         if (tile < total_tiles) {
             decode(tile, n, ty0, tx0);
-            tile_masks(ty0, tx0, dymask, pmask);
-            const unsigned dyo = dy_tile_off(n, ty0, tx0), xo = x_tile_off(n, ty0, tx0);
-    #pragma unroll
-            for (int i = 0; i < kWrDySlots; ++i) load_dy(i, dyo, dymask);
-    #pragma unroll
-            for (int i = 0; i < kWrInSlots; ++i) load_x(i, xo, pmask);
-            load_aff(n);
-            decode(min(tile + (int)gridDim.y, last_tile), n, ty0, tx0);
-            commit_issue(smem, n, ty0, tx0);
+            load_all(S0, n, ty0, tx0);
+            decode(tile_at(tile + G), n, ty0, tx0);
+            load_all(S1, n, ty0, tx0);
+            decode(tile_at(tile + 2 * G), n, ty0, tx0);
+            commit_issue(S0, smem, n, ty0, tx0);
         }
         __syncthreads();
         WPT_DECL
         while (tile < total_tiles) {
-            const int nxt = tile + gridDim.y;
-            // registers hold tile nxt (or, behind the last tile, a re-load of it that lands in the buffer nobody reads)
-            decode(min(nxt + (int)gridDim.y, last_tile), n, ty0, tx0);
-            commit_issue(smem + (cur ^ 1) * kWrBuf, n, ty0, tx0);
+            // even step: S1 holds the next tile
+            decode(tile_at(tile + 3 * G), n, ty0, tx0);
+            commit_issue(S1, smem + (cur ^ 1) * kWrBuf, n, ty0, tx0);
             WPT_MARK(6)
             __syncthreads();
             WPT_MARK(5)
             cur ^= 1;
-            tile = nxt;
+            tile += G;
+            if (tile >= total_tiles) break;
+            // odd step: S0
+            decode(tile_at(tile + 3 * G), n, ty0, tx0);
+            commit_issue(S0, smem + (cur ^ 1) * kWrBuf, n, ty0, tx0);
+            WPT_MARK(6)
+            __syncthreads();
+            WPT_MARK(5)
+            cur ^= 1;
+            tile += G;
         }
         WPT_DUMP()
         return;
