@@ -12,9 +12,11 @@ backward (+ bucketed RCCL all-reduce when N>1) -> fused Adam -> no-grad SSIM met
 synthetic U[0,1) tensors resident in HBM; weights are the reference's Kaiming init.  The per-step
 `.item()` host syncs of the reference are not reproduced (nothing is read back inside the timed region).
 
-Prints ONE JSON line on rank 0 (see the repo prompt for the schema) with two extra objects:
-`roofline` for the dominant kernel (largest total time among the live-timed convolution kernels) and
-`cpu_baseline` (the oracle port timed on this box's host cores, rank 0 at N=1 only).
+Prints ONE JSON line on rank 0 (see the repo prompt for the schema) with extra objects:
+`roofline` for the dominant MFMA kernel (largest total time among the live-timed convolution kernels),
+`roofline_hbm` for the dominant bandwidth-bound kernel (largest total time among the live-timed element-wise / reduction
+launches, achieved = algorithmic bytes / time against the 8 TB/s HBM peak), `conv_ms_per_step` / `elementwise_ms_per_step`
+(sums of the same instrumented pass) and `cpu_baseline` (the oracle port timed on this box's host cores, rank 0 at N=1 only).
 """
 import argparse
 import hashlib
@@ -30,6 +32,17 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_TBPS = 8.0                                                     # HBM3E spec peak, same guide (6.3 TB/s measured achievable)
+# entry point of a bandwidth-bound launch -> substring of the kernel symbol rocprofv3 / profiles/pmc_traffic.json report
+ENTRY_KERNEL = {"mrisr_act_bwd_reduce": "act_bwd_reduce_kernel", "mrisr_act_bwd_apply_fused": "act_bwd_apply_fused_kernel",
+                "mrisr_act_bwd_apply_fused_unshuffle": "act_bwd_unshuffle_window_kernel", "mrisr_act_bwd_apply": "act_bwd_apply_kernel",
+                "mrisr_norm_pool2": "norm_pool2_kernel", "mrisr_norm_upsample2": "norm_upsample2_kernel",
+                "mrisr_norm_blend": "norm_blend_kernel", "mrisr_upsample2_stats": "upsample2_stats_kernel",
+                "mrisr_upsample2_adjoint": "upsample2_adjoint_kernel", "mrisr_head_forward": "head_fwd_kernel",
+                "mrisr_stem_forward": "stem_fwd_kernel", "mrisr_stem_wgrad": "stem_wgrad_kernel",
+                "mrisr_ssim_l1_forward": "ssim_l1_fwd_kernel", "mrisr_ssim_l1_backward": "ssim_l1_bwd_kernel",
+                "mrisr_adam_step": "adam_kernel", "mrisr_adam_step_amp": "adam_amp_kernel",
+                "mrisr_pack_weights_batched": "pack_weights_batched_kernel", "mrisr_channel_sum": "channel_sum_kernel"}
 METRIC = "2D MRI slices/sec (train fwd+bwd) 256×256 U-Net; PSNR/SSIM vs ref"
 
 
@@ -168,6 +181,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    from mri_superresolution_amd import _lib as mrisr_lib
     from mri_superresolution_amd.engine import KernelTimer
     from mri_superresolution_amd.models.unet_model import UNetSuperRes
     from mri_superresolution_amd.optim import FusedAdam
@@ -259,7 +273,7 @@ def main():
     timer = None
     timed_steps = 0
     if not args.no_kernel_timer:            # every rank steps (the step holds collectives); rank 0 reports
-        timer = model._engine.timer = KernelTimer()
+        timer = model._engine.timer = mrisr_lib.timer = KernelTimer()     # convolutions by variant, L.call(nbytes=) launches by entry
         if vgg_eng is not None:
             vgg_eng.timer = timer
         timed_steps = min(args.steps, 10)
@@ -268,7 +282,7 @@ def main():
             step()
         torch.cuda.synchronize()
         timed_elapsed = time.perf_counter() - t1
-        model._engine.timer = None
+        model._engine.timer = mrisr_lib.timer = None
         if vgg_eng is not None:
             vgg_eng.timer = None
     # ---- step time WITHOUT the gradient exchange (same steps, all-reduce skipped: ranks diverge, timing only)
@@ -345,7 +359,35 @@ def main():
                                  "ms_per_step_with_exchange": round(ms, 3),
                                  "ms_per_step_without_exchange": None if noex_elapsed is None else round(noex_elapsed / args.steps * 1e3, 3)}
         if timer is not None:
-            summ = timer.summary()
+            allk = timer.summary()
+            summ = {k: v for k, v in allk.items() if v["flops_per_launch"] > 0}       # MFMA kernels (convolutions)
+            ew = {k: v for k, v in allk.items() if v["flops_per_launch"] == 0}        # bandwidth-bound launches
+            rec["conv_ms_per_step"] = round(sum(v["total_ms"] for v in summ.values()) / max(timed_steps, 1), 3)
+            rec["elementwise_ms_per_step"] = round(sum(v["total_ms"] for v in ew.values()) / max(timed_steps, 1), 3)
+            table, prov = pmc_traffic()
+
+            def pmc_bytes(entry):
+                """PMC traffic per launch of the kernel behind an entry point (None when the table is stale / lacks it)."""
+                if table is None:
+                    return None
+                sub = ENTRY_KERNEL.get(entry, entry)
+                hits = [v.get("hbm_bytes_per_launch") for k, v in table.get("kernels", {}).items() if sub in k]
+                hits = [h for h in hits if h]
+                return round(sum(hits) / len(hits)) if hits else None
+            if ew:
+                ename, edom = max(ew.items(), key=lambda kv: kv[1]["total_ms"])
+                rec["roofline_hbm"] = {"bound": "hbm", "kernel": ENTRY_KERNEL.get(ename, ename), "entry": ename,
+                                       "achieved": round(edom["tbps"], 3), "peak": HBM_PEAK_TBPS, "unit": "TB/s",
+                                       "frac": round(edom["tbps"] / HBM_PEAK_TBPS, 4),
+                                       "bytes_per_launch": round(edom["bytes_per_launch"]),
+                                       "traffic": pmc_bytes(ename), "traffic_provenance": prov,
+                                       "launches": edom["launches"], "us_per_launch": round(edom["ms_per_launch"] * 1e3, 2),
+                                       "what": "achieved = ALGORITHMIC bytes (every tensor the launch reads or writes, once) / HIP-event "
+                                               "time of the same instrumented pass; an entry point may cover several template "
+                                               "instantiations (e.g. the GroupNorm-backward passes of all 20 nodes)"}
+                rec["elementwise"] = {ENTRY_KERNEL.get(k, k): {"launches": v["launches"], "us_per_launch": round(v["ms_per_launch"] * 1e3, 2),
+                                                               "tbps": round(v["tbps"], 3), "share_of_step": round(v["total_ms"] / (timed_elapsed * 1e3), 4)}
+                                      for k, v in sorted(ew.items(), key=lambda kv: -kv[1]["total_ms"])}
             if summ:
                 name, dom = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
                 peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -353,14 +395,13 @@ def main():
                                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": None,
                                    "launches": dom["launches"], "us_per_launch": round(dom["ms_per_launch"] * 1e3, 2),
                                    "flops_per_launch": dom["flops_per_launch"],
-                                   "timing": f"HIP events on the launch stream, separate pass of {timed_steps} steps "
+                                   "timing": f"the dominant kernel is picked among the live-timed CONVOLUTION kernels; HIP events on the launch stream, separate pass of {timed_steps} steps "
                                              f"({timed_elapsed / timed_steps * 1e3:.3f} ms/step instrumented), ONE stream, "
                                              "every persistent kernel sized for the whole chip (the headline region runs "
                                              "the weight gradients on a second stream, each kind on half the CUs); a "
-                                             "conv_wgrad entry = conv_wgrad_kernel + its wgrad_reduce_kernel (two-stage "
-                                             "split-K) timed as one unit; rocprofv3 counterpart: "
-                                             "profiles/r02_step_kernel_stats_single_stream.csv"}
-                table, prov = pmc_traffic()
+                                             "conv_wgrad entry = the weight-gradient kernel + its split-K reduce kernel timed "
+                                             "as one unit; rocprofv3 counterpart: "
+                                             "profiles/r03_step_kernel_stats_single_stream.csv"}
                 rec["roofline"]["traffic_provenance"] = prov
                 if table is not None:
                     rec["roofline"]["traffic"] = table.get("kernels", {}).get(name, {}).get("hbm_bytes_per_launch")

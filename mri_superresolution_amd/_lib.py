@@ -154,7 +154,15 @@ def check(rc: int, what: str = ""):
         raise RuntimeError(f"libmrisr {what} failed ({rc}): {msg}")
 
 
-def call(name: str, *args):
+timer = None      # engine.KernelTimer while bench.py's instrumented pass runs (never in the product path)
+
+
+def call(name: str, *args, nbytes=None):
+    """Launches entry point ``name``.  ``nbytes`` (optional): ALGORITHMIC HBM bytes of a bandwidth-bound launch (every tensor
+    read or written once); when a KernelTimer is active such launches are bracketed by HIP events on the launch stream."""
+    if timer is not None and nbytes is not None and timer.enabled:
+        timer.launch(name, 0.0, lambda: check(getattr(load(), name)(*args), name), nbytes=float(nbytes))
+        return
     check(getattr(load(), name)(*args), name)
 
 

@@ -100,29 +100,39 @@ class KernelTimer:
     grouping `rocprofv3 --kernel-trace --stats` reports."""
 
     def __init__(self):
-        self.records = []          # (name, flops, start_event, end_event)
+        self.records = []          # (name, flops, bytes, start_event, end_event)
         self.enabled = True
 
-    def launch(self, name: str, flops: float, fn):
+    def launch(self, name: str, flops: float, fn, nbytes: float = 0.0):
         if not self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
-        self.records.append((name, flops, a, b))
+        self.records.append((name, flops, nbytes, a, b))
+
+    def __enter__(self):
+        L.timer = self             # bandwidth-bound launches (L.call(..., nbytes=)) are timed as well
+        return self
+
+    def __exit__(self, *exc):
+        L.timer = None
 
     def summary(self):
-        """name -> dict(launches, flops_per_launch, ms_per_launch, tflops); call after a device sync."""
+        """name -> dict(launches, flops_per_launch, bytes_per_launch, ms_per_launch, tflops, tbps); call after a device sync.
+        Convolutions carry FLOPs (names = kernel instantiations), bandwidth-bound launches algorithmic bytes (names = entry points)."""
         agg = {}
-        for name, flops, a, b in self.records:
-            e = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, flops, nbytes, a, b in self.records:
+            e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             e[0] += 1
             e[1] += flops
             e[2] += a.elapsed_time(b)
-        return {k: {"launches": n, "flops_per_launch": fl / n, "ms_per_launch": ms / n,
-                    "total_ms": ms, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
-                for k, (n, fl, ms) in agg.items()}
+            e[3] += nbytes
+        return {k: {"launches": n, "flops_per_launch": fl / n, "bytes_per_launch": by / n, "ms_per_launch": ms / n,
+                    "total_ms": ms, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                    "tbps": by / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+                for k, (n, fl, ms, by) in agg.items()}
 
 
 class UNetEngine:
@@ -239,11 +249,14 @@ class UNetEngine:
                         j.w, j.packed, j.Cout, j.Cin, j.ksize, j.transpose_flip = (w.data_ptr(), buf.data_ptr(), layer.cout, layer.cin,
                                                                                    layer.ks, flip | L.PACK_RING)
                         i += 1
+            # algorithmic traffic of the launch: every fp32 master once per image built from it + every image written once
+            self._jobs_bytes = sum(4 * params[l.name + ".weight"].numel() for l in self.layers) * 2 + \
+                sum(b.numel() for k, b in self._packed.items() if k[1] == dt)
             host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
             self._jobs_dev = host.to(dev)
             self._jobs_n = i
             self._jobs_key = key
-        L.call("mrisr_pack_weights_batched", dt, self._jobs_dev.data_ptr(), self._jobs_n, stream)
+        L.call("mrisr_pack_weights_batched", dt, self._jobs_dev.data_ptr(), self._jobs_n, stream, nbytes=self._jobs_bytes)
         self._packed_token = (dt, token)
 
     # ------------------------------------------------------------------ descriptors
@@ -292,6 +305,7 @@ class UNetEngine:
         dt = _dt(dtype)
         dev = x.device
         N, _, H, W = x.shape
+        es = 4 if dtype == torch.float32 else 2        # bytes per stored activation element (algorithmic-traffic bookkeeping)
         mins = 2 ** (self.depth - 1)
         if H < mins or W < mins:
             raise ValueError(f"input must be at least {mins}x{mins} ({self.depth - 1} 2x2 max-pools)")
@@ -320,7 +334,7 @@ class UNetEngine:
         s.N, s.H, s.W = N, H, W
         s.raw = torch.empty((N, H, W, f), dtype=dtype, device=dev)
         L.call("mrisr_stem_forward", dt, x.data_ptr(), params["inc.double_conv.0.weight"].data_ptr(),
-               s.raw.data_ptr(), s.stats.data_ptr(), N, H, W, f, GN_GROUPS, st)
+               s.raw.data_ptr(), s.stats.data_ptr(), N, H, W, f, GN_GROUPS, st, nbytes=N * H * W * (4 + f * es))
         finalize(s)
 
         for layer in self.layers:
@@ -331,13 +345,13 @@ class UNetEngine:
                 vh, vw = sn.H // 2, sn.W // 2
                 layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
                 L.call("mrisr_norm_pool2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
-                       layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st)
+                       layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st, nbytes=N * sn.H * sn.W * sn.C * es * 1.25)
             if layer.up_src:
                 sn = layer.srcs[0].node
                 vh, vw = 2 * sn.H, 2 * sn.W
                 layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
                 L.call("mrisr_norm_upsample2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
-                       layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st)
+                       layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st, nbytes=N * sn.H * sn.W * sn.C * es * 5)
             if layer.blend_src:
                 a, b = layer.srcs[0].node, layer.srcs[1].node
                 if (a.H, a.W, a.C) != (b.H, b.W, b.C):
@@ -345,7 +359,7 @@ class UNetEngine:
                 layer.aux = torch.empty((N, a.H, a.W, a.C), dtype=dtype, device=dev)
                 L.call("mrisr_norm_blend", dt, a.raw.data_ptr(), a.scale.data_ptr(), a.shift.data_ptr(), b.raw.data_ptr(),
                        b.scale.data_ptr(), b.shift.data_ptr(), params["alpha"].data_ptr(), layer.aux.data_ptr(),
-                       N, a.H, a.W, a.C, st)
+                       N, a.H, a.W, a.C, st, nbytes=N * a.H * a.W * a.C * es * 3)
             layer.H, layer.W = vh, vw
             layer.offs = []
             for sidx, src in enumerate(layer.srcs):
@@ -373,14 +387,14 @@ class UNetEngine:
             self._launch("fwd", d, lambda: L.call("mrisr_conv_forward", C.byref(d), st))
             if layer.post_up:
                 L.call("mrisr_upsample2_stats", dt, zlow.data_ptr(), o.raw.data_ptr(), o.stats.data_ptr(),
-                       N, vh, vw, o.C, GN_GROUPS, st)
+                       N, vh, vw, o.C, GN_GROUPS, st, nbytes=N * vh * vw * o.C * es * 5)
             finalize(o)
 
         hn = self.head_in
         out = torch.empty((N, 1, hn.H, hn.W), dtype=torch.float32, device=dev)
         L.call("mrisr_head_forward", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
                params["final_conv.3.weight"].data_ptr(), params["final_conv.3.bias"].data_ptr(), out.data_ptr(),
-               N, hn.H, hn.W, hn.C, st)
+               N, hn.H, hn.W, hn.C, st, nbytes=N * hn.H * hn.W * (hn.C * es + 4))
         ctx = None
         if training:
             ctx = {"x": x, "out": out, "dtype": dtype, "N": N, "arena": arena,
@@ -400,6 +414,7 @@ class UNetEngine:
         (reverse execution order) so that a data-parallel driver can start its all-reduce."""
         dtype = ctx["dtype"]
         dt = _dt(dtype)
+        es = 4 if dtype == torch.float32 else 2
         N = ctx["N"]
         x = ctx["x"]
         dev = x.device
@@ -454,9 +469,13 @@ class UNetEngine:
             # the two branches' reduce passes (sum dain*act each), no extra pass over the three tensors
             wm0 = n.consumers[0][8]
             slots = red[N * n.C * 2:] if (wm0 != 0 and n.consumers[0][5] == L.SP_NONE) else None
+            # algorithmic traffic of the two passes: x once per pass, every consumer gradient once per pass (the channel window
+            # the node owns; a pooled consumer's is a quarter of the node's size, the head's two one-channel fp32 maps), dx once
+            nx = N * n.H * n.W * n.C * es
+            nda = sum(N * c[3] * c[4] * (8 if c[5] == L.SP_HEAD else n.C * es) for c in n.consumers)
             L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
                    n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(), L.ptr(slots),
-                   N, n.H, n.W, n.C, GN_GROUPS, st)
+                   N, n.H, n.W, n.C, GN_GROUPS, st, nbytes=nx + nda + (nx if g is not None else 0))
             count = float((n.C // GN_GROUPS) * n.H * n.W)
             dalpha_ptr = grads["alpha"].data_ptr() if slots is not None else None
             if fused or fused_ps:
@@ -467,12 +486,14 @@ class UNetEngine:
                 if fused_ps:
                     dx = torch.empty((N, n.H // 2, n.W // 2, 4 * n.C), dtype=dtype, device=dev)
                     L.call("mrisr_act_bwd_apply_fused_unshuffle", dt, n.raw.data_ptr(), n.scale.data_ptr(),
-                           n.shift.data_ptr(), cons, alpha_ptr, C.byref(fin), dx.data_ptr(), L.ptr(dbias), N, n.H, n.W, n.C, st)
+                           n.shift.data_ptr(), cons, alpha_ptr, C.byref(fin), dx.data_ptr(), L.ptr(dbias), N, n.H, n.W, n.C, st,
+                           nbytes=2 * nx + nda)
                     n.consumers = []
                     return dx
                 dx = torch.empty_like(n.raw)
                 L.call("mrisr_act_bwd_apply_fused", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
-                       len(n.consumers), cons, alpha_ptr, None, C.byref(fin), dx.data_ptr(), N, n.H, n.W, n.C, st)
+                       len(n.consumers), cons, alpha_ptr, None, C.byref(fin), dx.data_ptr(), N, n.H, n.W, n.C, st,
+                       nbytes=2 * nx + nda)
                 n.consumers = []
                 return dx
             coef = torch.empty(3 * N * n.C, dtype=torch.float32, device=dev)
@@ -486,7 +507,7 @@ class UNetEngine:
                 dx = torch.empty_like(n.raw)
                 mode = L.OUT_PLAIN
             L.call("mrisr_act_bwd_apply", dt, n.raw.data_ptr(), g.data_ptr(), coef.data_ptr(), dx.data_ptr(),
-                   N, n.H, n.W, n.C, mode, L.ptr(dbias) if n.shuffled else None, st)
+                   N, n.H, n.W, n.C, mode, L.ptr(dbias) if n.shuffled else None, st, nbytes=3 * nx)
             n.consumers = []
             return dx
 
@@ -529,7 +550,8 @@ class UNetEngine:
                 bucket_hook("final_conv.3")       # the head's dW / db came out of that node's first pass
             if layer.post_up:       # adjoint of the bilinear x2 that follows the low-resolution 1x1 conv
                 dyl = torch.empty((N, layer.H, layer.W, layer.cout), dtype=dtype, device=dev)
-                L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st)
+                L.call("mrisr_upsample2_adjoint", dt, dy.data_ptr(), dyl.data_ptr(), N, layer.H, layer.W, layer.cout, st,
+                       nbytes=N * layer.H * layer.W * layer.cout * es * 5)
                 dy = dyl
             d = self._desc(layer, dt, N, params)
             need = L.load().mrisr_conv_wgrad_workspace_floats(C.byref(d))
@@ -554,7 +576,7 @@ class UNetEngine:
                 launch_wgrad()
             if layer.bias and not fuse_bias:
                 L.call("mrisr_channel_sum", dt, dy.data_ptr(), grads[layer.name + ".bias"].data_ptr(),
-                       N * layer.H * layer.W, layer.cout, st)
+                       N * layer.H * layer.W, layer.cout, st, nbytes=N * layer.H * layer.W * layer.cout * es)
             # input gradient: the same implicit-GEMM kernel on dy with mirrored, transposed weights
             dd = L.ConvDesc()
             dd.dtype, dd.N, dd.H, dd.W = dt, N, layer.H, layer.W
@@ -582,7 +604,8 @@ class UNetEngine:
                 # low-resolution gradient); the 4x4 gather inside act_bwd_reduce ran at a third of this rate
                 sn = layer.srcs[0].node
                 dlow = torch.empty((N, sn.H, sn.W, layer.cin), dtype=dtype, device=dev)
-                L.call("mrisr_upsample2_adjoint", dt, dain.data_ptr(), dlow.data_ptr(), N, sn.H, sn.W, layer.cin, st)
+                L.call("mrisr_upsample2_adjoint", dt, dain.data_ptr(), dlow.data_ptr(), N, sn.H, sn.W, layer.cin, st,
+                       nbytes=N * sn.H * sn.W * layer.cin * es * 5)
                 sn.consumers.append((dlow, layer.cin, 0, sn.H, sn.W, L.SP_NONE, 0, 0, 0))
             else:
                 coff = 0
@@ -596,7 +619,7 @@ class UNetEngine:
         # stem (no input gradient: the image needs none)
         dy = node_backward(self.stem)
         L.call("mrisr_stem_wgrad", dt, x.data_ptr(), dy.data_ptr(), grads["inc.double_conv.0.weight"].data_ptr(),
-               N, self.stem.H, self.stem.W, self.f, st)
+               N, self.stem.H, self.stem.W, self.f, st, nbytes=N * self.stem.H * self.stem.W * (4 + self.f * es))
         if bucket_hook:
             bucket_hook("inc.double_conv.0")
         if side is not None:

@@ -65,13 +65,13 @@ class FusedAdam(torch.optim.Optimizer):
             L.call("mrisr_adam_step_amp", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                    self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
                    float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step_dev.data_ptr(),
-                   float(self.dp_grad_scale), L.ptr(ls), L.ptr(fi), L.stream_ptr())
+                   float(self.dp_grad_scale), L.ptr(ls), L.ptr(fi), L.stream_ptr(), nbytes=28 * m.flat_params.numel())
         else:
             self._step += 1
             L.call("mrisr_adam_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                    self.exp_avg_sq.data_ptr(), m.flat_params.numel(), float(g["lr"]), float(g["betas"][0]),
                    float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, float(self.dp_grad_scale),
-                   L.stream_ptr())
+                   L.stream_ptr(), nbytes=28 * m.flat_params.numel())
         m.mark_weights_changed()        # the kernel wrote the masters through raw pointers: packed images are stale
         return loss
 

@@ -74,8 +74,10 @@ class _SSIML1(torch.autograd.Function):
         else:
             sums = torch.zeros(planes * 2, dtype=torch.float64, device=a.device)
             coef = torch.empty(3 * planes * h * w, dtype=torch.float32, device=a.device) if (need_grad and ssim_w != 0) else None
+            # algorithmic traffic: the two fp32 images once (8 B per pixel) + the three coefficient planes kept
+            # for the backward pass when a gradient is wanted
             L.call("mrisr_ssim_l1_forward", a.data_ptr(), b.data_ptr(), sums.data_ptr(), L.ptr(coef), planes, h, w,
-                   float(val_range), float(sigma), st)
+                   float(val_range), float(sigma), st, nbytes=planes * h * w * (8 + (12 if coef is not None else 0)))
             _last_sums = (key, sums, a, b)
         comp = torch.empty(3 + planes, dtype=torch.float32, device=a.device)
         L.call("mrisr_loss_finalize", sums.data_ptr(), planes, h, w, float(l1_w), float(ssim_w), comp.data_ptr(), st)
@@ -93,7 +95,8 @@ class _SSIML1(torch.autograd.Function):
         da = torch.empty_like(a)
         if kind == 0:
             L.call("mrisr_ssim_l1_backward", a.data_ptr(), b.data_ptr(), L.ptr(coef), sums.data_ptr(), g.data_ptr(),
-                   l1_w, ssim_w, da.data_ptr(), planes, h, w, sigma, L.stream_ptr())
+                   l1_w, ssim_w, da.data_ptr(), planes, h, w, sigma, L.stream_ptr(),
+                   nbytes=planes * h * w * (12 + (12 if coef is not None else 0)))
         else:   # d(mean ssim): weights (0, -1), no clamp
             L.call("mrisr_ssim_l1_backward", a.data_ptr(), b.data_ptr(), L.ptr(coef), None, g.data_ptr(),
                    0.0, -1.0, da.data_ptr(), planes, h, w, sigma, L.stream_ptr())

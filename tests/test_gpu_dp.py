@@ -96,3 +96,25 @@ def test_two_rank_training_equals_single_process(tmp_path):
     if os.path.isdir(d):
         with open(os.path.join(d, "parity_report.txt"), "a") as fh:
             fh.write("\n".join(l for l in r.stdout.splitlines() if l.startswith("OK rank")) + "\n")
+
+
+def test_bench_rccl_rehearsal_through_the_launcher():
+    """The RCCL transport of the data-parallel step on this one-GPU box: `bench.py --gpus 1` started through
+    torch.distributed.run with MRISR_FORCE_DP=1 (a fresh child process; this test process never re-launches itself) must
+    report the collective block - backend nccl, the 4 suffix buckets of the f = 64 model, 29,140,128 gradient bytes per
+    step and the step time with and without the exchange."""
+    import json
+    sys.path.insert(0, REPO)
+    import bench
+    cmd = bench.rank_launch_command(1, ["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timer",
+                                        "--no-forward-metric"], bench.free_port())
+    env = dict(os.environ, MRISR_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    c = rec["collective"]
+    assert c["backend"] == "nccl" and c["world"] == 1
+    assert c["buckets"] == 4 and c["allreduce_bytes_per_step"] == 29140128
+    assert c["ms_per_step_with_exchange"] > 0 and c["ms_per_step_without_exchange"] > 0
+    assert rec["n_gpus"] == 1 and rec["config"]["parallelism"] == "dp1"

@@ -217,6 +217,40 @@ def test_data_parallel_bucketed_allreduce_gloo_world2(tmp_path):
     assert r.stdout.count("OK") == 2
 
 
+def _bucket_sequence(base_filters, depth=4):
+    """(lo, hi) element ranges in the order GradBucketer would all-reduce them for one backward pass of the engine's
+    schedule (head first, then the layers in reverse execution order, then the stem) - no process group needed."""
+    from mri_superresolution_amd.models.unet_model import UNetSuperRes
+    from mri_superresolution_amd.parallel import GradBucketer
+    m = UNetSuperRes(1, 1, base_filters, depth=depth)
+    b = GradBucketer(m.flat_grads, m._offsets)
+    seq = []
+    b._launch = lambda lo, hi: seq.append((lo, hi))        # record instead of dist.all_reduce
+    hooks = ["final_conv.3"] + [l.name for l in reversed(m._engine.layers)] + ["inc.double_conv.0"]   # engine.backward's order
+    for name in hooks:
+        b.on_layer_done(name)
+    b.flush_down_to(0)                                     # what finish() does before waiting
+    return seq, m.flat_grads.numel()
+
+
+@pytest.mark.parametrize("f,depth,nbuckets,nbytes", [(64, 4, 4, 29140128), (128, 5, None, None)])
+def test_collective_sequence_is_identical_on_every_rank(f, depth, nbuckets, nbytes):
+    """Data parallelism over 8 GPUs: every rank must issue the SAME all-reduce calls in the SAME order
+    (a collective is matched by its position in the sequence) - the bucket bounds and their launch order are a pure
+    function of the model's layout, never of the rank, its random initialisation or its data."""
+    seqs = []
+    for rank in range(8):
+        torch.manual_seed(1000 + rank)                     # different initial weights per "rank": must not matter
+        seq, total = _bucket_sequence(f, depth)
+        seqs.append(seq)
+        # the buckets tile the flat gradient exactly once, from the end towards the start
+        assert seq[0][1] == total and seq[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(seq, seq[1:])) and all(lo < hi for lo, hi in seq)
+    assert all(s == seqs[0] for s in seqs[1:])
+    if nbuckets is not None:
+        assert len(seqs[0]) == nbuckets and seqs[0][0][1] * 4 == nbytes
+
+
 def test_bench_self_launch_command():
     """`python bench.py --gpus N` typed directly: the parent never touches the GPU, it spawns torch.distributed.run."""
     sys.path.insert(0, REPO)

@@ -23,14 +23,24 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def _t(code):
+    return {"DF16b": "bf16", "DF16_": "f16", "f": "f32"}[code]
+
+
 def demangle_conv(name):
-    m = re.match(r"_Z17conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])EEv10ConvParams", name)
+    m = re.match(r"_Z16conv_ring_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)ELb[01]EEv10RingParams", name)
+    if m:      # (the two statistics variants are one bench entry)
+        return f"conv_ring_kernel<{_t(m.group(1))},{m.group(2)},{m.group(3)}>"
+    m = re.match(r"_Z22conv_wgrad_rows_kernelI(DF16b|DF16_)Ev10ConvParams", name)
     if m:
-        t = "bf16" if m.group(1) == "DF16b" else "f32"
+        return f"conv_wgrad_rows_kernel<{_t(m.group(1))}>"
+    m = re.match(r"_Z17conv_igemm_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])EEv10ConvParams", name)
+    if m:
+        t = _t(m.group(1))
         return f"conv_igemm_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)},{m.group(6)},{m.group(7)}>"
-    m = re.match(r"_Z17conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEv10ConvParams", name)
+    m = re.match(r"_Z17conv_wgrad_kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)EEv10ConvParams", name)
     if m:
-        t = "bf16" if m.group(1) == "DF16b" else "f32"
+        t = _t(m.group(1))
         return f"conv_wgrad_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)}>"
     return re.sub(r"\(.*", "", name)
 
