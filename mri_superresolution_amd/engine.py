@@ -40,7 +40,8 @@ def _dt(dtype: torch.dtype) -> int:
 # (measured at C2 on one box, A/B alternating: one stream 9.70 ms/step; second stream, every kernel sized for the whole
 # chip 9.52; second stream + half the CUs each 9.31; 64 CUs for the weight gradients: 10.8, 96: 9.35, 144: 9.36-9.49,
 # 160: 9.58, 192: 10.8; input gradient first on the whole chip with the weight gradient behind it on 128-224 CUs:
-# 9.33-9.41 - the two kinds of kernel also compete for HBM and for the power budget).
+# 9.33-9.41 - the two kinds of kernel also compete for HBM and for the power budget).  Round 3, with the row-streaming weight
+# gradient: 64 CUs 9.81 ms, 72: 8.75, 80: 8.72, 88: 8.72-8.74, 96: 8.70, 104: 8.75, 112: 8.82, 128: 8.82-8.86, 144: 9.29 -> 3/8 of the chip.
 _WGRAD_LAST = TUNING.wgrad_last
 _WGRAD_STREAM = TUNING.wgrad_stream
 _WGRAD_CUS = TUNING.wgrad_cus
@@ -522,7 +523,7 @@ class UNetEngine:
         # second stream for the weight gradients (not while kernels are being timed with events on the main stream)
         side = None
         main = torch.cuda.current_stream()
-        side_cus = L.num_cus() // 2 if _WGRAD_CUS < 0 else _WGRAD_CUS
+        side_cus = L.num_cus() * 3 // 8 if _WGRAD_CUS < 0 else _WGRAD_CUS
         if _WGRAD_STREAM and self.timer is None:
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != dev:
