@@ -170,6 +170,11 @@ int mrisr_norm_blend(int dtype, const void* x0, const float* scale0, const float
  * tensor this evaluates nn.Upsample -> nn.Conv2d(1x1) (unet_model.py:71-72) as conv -> upsample.           */
 int mrisr_upsample2_stats(int dtype, const void* z_low, void* z, double* stats, int N, int h, int w, int C,
                           int groups, void* stream);
+/* The same pair in ONE launch for 16-bit storage: z [N][2h][2w][Cout] = bilinear x2 of conv1x1(LeakyReLU(x*scale+shift)) and
+ * the GroupNorm statistics of z, the low-resolution tensor staying in LDS (csrc/up_fused.hip).  x [N][h][w][Cin] raw,
+ * scale / shift [N][Cin], wpacked = mrisr_pack_weights image of the (Cout,Cin,1,1) weight; Cin % 32 == 0, Cout % 64 == 0.   */
+int mrisr_up_conv1x1_fused(int dtype, const void* x, const float* scale, const float* shift, const void* wpacked, void* z,
+                           double* stats, int N, int h, int w, int Cin, int Cout, int groups, void* stream);
 /* adjoint of the above interpolation: dz [N][2h][2w][C] -> dz_low [N][h][w][C]                              */
 int mrisr_upsample2_adjoint(int dtype, const void* dz, void* dz_low, int N, int h, int w, int C, void* stream);
 

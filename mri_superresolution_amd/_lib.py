@@ -84,6 +84,7 @@ SIGNATURES = {
     "mrisr_norm_upsample2": (_i, [_i, _vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_norm_blend": (_i, [_i, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_upsample2_stats": (_i, [_i, _vp, _vp, _dp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_up_conv1x1_fused": (_i, [_i, _vp, _fp, _fp, _vp, _vp, _dp, _i, _i, _i, _i, _i, _i, _vp]),
     "mrisr_upsample2_adjoint": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_act_bwd_reduce": (_i, [_i, _vp, _fp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_act_bwd_finalize": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _fp, _fp, _fp, _f, _vp]),
@@ -116,7 +117,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 300      # mrisr_version() of the library these struct layouts and signatures belong to
+ABI_VERSION = 301      # mrisr_version() of the library these struct layouts and signatures belong to
 
 
 def load():

@@ -380,6 +380,20 @@ class UNetEngine:
             d.wpacked = self._packed[(layer.name, dt, 0)].data_ptr()
             d.wpacked_ring = L.ptr(self._packed.get((layer.name, dt, 0, "ring")))
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
+            if layer.post_up and es == 2 and layer.cin % 32 == 0 and layer.cout % 64 == 0 and not TUNING.no_up_fused:
+                # 16-bit storage: conv1x1 at low resolution + bilinear x2 + statistics in ONE launch (csrc/up_fused.hip);
+                # the low-resolution tensor never goes to HBM
+                sn = layer.srcs[0].node
+                fl = 2.0 * N * vh * vw * layer.cin * layer.cout
+                call = lambda: L.call("mrisr_up_conv1x1_fused", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
+                                      d.wpacked, o.raw.data_ptr(), o.stats.data_ptr(), N, vh, vw, layer.cin, layer.cout,
+                                      GN_GROUPS, st)
+                if self.timer is None:
+                    call()
+                else:
+                    self.timer.launch("up1x1_fused_kernel<%s>" % ("bf16" if dt == L.BF16 else "f16"), fl, call)
+                finalize(o)
+                continue
             if layer.post_up:
                 zlow = torch.empty((N, vh, vw, o.C), dtype=dtype, device=dev)
                 d.out, d.stats = zlow.data_ptr(), None

@@ -12,6 +12,8 @@ that `tools/` can A/B schedules on one box without editing the package.  libmris
   MRISR_SIDE_PRIO      priority of the second stream (default -1 = high: its own hardware queue class)
   MRISR_NO_RING        1: the engine hands no ring-layout weight images over, i.e. every convolution runs the classic
                        conv_igemm kernels (A/B of csrc/conv_ring.hip inside the training step)
+  MRISR_NO_UP_FUSED    1: the decoder's 1x1 conv + bilinear x2 + statistics run as two launches (mrisr_conv_forward at low
+                       resolution + mrisr_upsample2_stats) instead of csrc/up_fused.hip
   MRISR_FORCE_DP       1: bench.py / scripts wrap the model in DataParallel even at world size 1 (rehearses the RCCL path)
 """
 from __future__ import annotations
@@ -40,6 +42,7 @@ class Tuning:
     side_prio: int
     force_dp: bool
     no_ring: bool
+    no_up_fused: bool
 
 
 def _read() -> Tuning:
@@ -52,6 +55,7 @@ def _read() -> Tuning:
         side_prio=_int("MRISR_SIDE_PRIO", -1),
         force_dp=_int("MRISR_FORCE_DP", 0) == 1,
         no_ring=_int("MRISR_NO_RING", 0) == 1,
+        no_up_fused=_int("MRISR_NO_UP_FUSED", 0) == 1,
     )
 
 

@@ -656,6 +656,34 @@ def test_norm_pool2_and_upsample2(dt, shape):
     assert U.relerr(U.nchw(dzl), xr.grad) <= TOL_OUT[dt]
 
 
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 11, 19), (1, 128, 256, 32, 32), (2, 96, 128, 8, 5), (1, 32, 64, 1, 3)])
+def test_up_conv1x1_fused(dt, shape):
+    """csrc/up_fused.hip: bilinear x2 (align_corners) of conv1x1(LeakyReLU(GroupNorm(x))) + GroupNorm statistics in one launch,
+    against nn.Upsample -> nn.Conv2d(1x1) evaluated in the reference's order (unet_model.py:71-72) - the two linear maps
+    commute; the fused kernel rounds the low-resolution conv output to the storage type like the two-launch form."""
+    n, cin, cout, h, w = shape
+    x, wt = rnd(n, cin, h, w, seed=88), rnd(cout, cin, 1, 1, seed=89, scale=0.15)
+    sc, sh = gn_affine(n, cin, 90)
+    xd, scd, shd = U.nhwc(x, dt), sc.to(U.DEV), sh.to(U.DEV)
+    wp = U.pack(wt, dt, 0)
+    z = torch.full((n, 2 * h, 2 * w, cout), float("nan"), dtype=U.tdt(dt), device=U.DEV)
+    stats = torch.zeros(L.STAT_SLOTS * n * 16, dtype=torch.float64, device=U.DEV)
+    L.call("mrisr_up_conv1x1_fused", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wp.data_ptr(), z.data_ptr(), stats.data_ptr(),
+           n, h, w, cin, cout, 8, U.stream())
+    torch.cuda.synchronize()
+    act = U.rounded(F.leaky_relu(U.rounded(x, dt) * sc.view(n, cin, 1, 1) + sh.view(n, cin, 1, 1), 0.2), dt)
+    ref = F.conv2d(F.interpolate(act, scale_factor=2, mode="bilinear", align_corners=True), U.rounded(wt, dt))
+    got = U.nchw(z)
+    assert torch.isfinite(got).all()
+    assert U.relerr(got, ref) <= TOL_NORM[dt]
+    # statistics of the tensor as stored (the kernel sums the fp32 interpolated values before rounding: storage tolerance)
+    o = got.view(n, 8, cout // 8, 2 * h, 2 * w).double()
+    st = stats.cpu().view(L.STAT_SLOTS, n, 8, 2).sum(0)
+    assert torch.allclose(st[..., 0], o.sum((2, 3, 4)), rtol=2e-3, atol=2e-2 * o.abs().max().item())
+    assert torch.allclose(st[..., 1], (o * o).sum((2, 3, 4)), rtol=5e-3)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape", [(2, 32, 11, 19), (1, 16, 1, 5), (1, 64, 32, 32), (1, 8, 256, 3)])
 def test_norm_upsample2(dt, shape):

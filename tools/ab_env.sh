@@ -1,12 +1,11 @@
 #!/bin/bash
-# A/B of environment settings on ONE box (alternating runs): tools/ab_env.sh <rounds> "<VAR=a>" "<VAR=b>" ... [-- bench args]
-R=$1; shift
-SETS=()
-while [ $# -gt 0 ] && [ "$1" != "--" ]; do SETS+=("$1"); shift; done
-[ "$1" == "--" ] && shift
-for r in $(seq $R); do
-  for S in "${SETS[@]}"; do
-    env $S timeout -k 10 150 python bench.py --no-cpu-baseline --no-kernel-timer --no-forward-metric --steps 30 "$@" 2>/dev/null | tail -1 \
-      | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$S', j['value'], j['ms_per_step'])"
+# In-step A/B of a host-side tuning switch on ONE box: tools/ab_env.sh MRISR_NO_UP_FUSED  -> bench.py alternating VAR unset / VAR=1
+var=$1
+for i in 1 2 3; do
+  for v in 0 1; do
+    if [ $v = 1 ]; then export $var=1; else unset $var; fi
+    timeout -k 10 200 python bench.py --no-cpu-baseline --no-kernel-timer --steps 30 2>/dev/null | tail -1 | python -c "
+import sys,json
+j=json.loads(sys.stdin.read()); print('round $i $var=$v', j['value'], 'slices/s', j['ms_per_step'], 'ms; fwd', j['forward']['slices_per_s'], j['forward']['ms_per_batch'])"
   done
 done
