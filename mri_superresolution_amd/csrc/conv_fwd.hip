@@ -1477,7 +1477,9 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     const char* t = d->dtype == MRISR_BF16 ? "bf16" : (d->dtype == MRISR_F16 ? "f16" : "f32");
     const int loader = d->combine == MRISR_COMBINE_BLEND ? 3 : d->src[0].spatial;
     if (wgrad && conv_wgrad_rows_ok(d)) {
-        snprintf(out, n, "conv_wgrad_rows_kernel<%s>", t);
+        bool raw = true;
+        for (int i = 0; i < d->nsrc; ++i) raw = raw && d->src[i].mode == MRISR_SRC_RAW;
+        snprintf(out, n, "conv_wgrad_rows_kernel<%s,%d,%d,%d>", t, d->Cout % 64 ? 1 : 2, d->Cin % 64 ? 1 : 2, raw ? 1 : 0);
     } else if (wgrad) {
         snprintf(out, n, "conv_wgrad_kernel<%s,%d,%d,%d>", t, loader, d->ksize,
                  conv_wgrad_fast(d->dtype, loader, d->ksize, p.tw_log2, d->Cout, d->Cin));

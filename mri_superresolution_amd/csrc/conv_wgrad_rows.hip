@@ -42,8 +42,9 @@ constexpr int kWrDyBytes = 256 * 128;          // [16 x 16 px][64 co] 128-B rows
 constexpr int kWrInRows = 18 * 18;             // halo tile
 constexpr int kWrInBytes = 352 * 128;          // [18 x 18 px][64 ci] (+ 28 rows so that the last staging slot stores unpredicated)
 constexpr int kWrBuf = kWrDyBytes + kWrInBytes;
-constexpr int kWrDySlots = 8;                  // 16-B vectors per staging thread: dy 256 px x 8 chunks / 256 threads
-constexpr int kWrInSlots = 11;                 //                                halo 324 px x 8 chunks / 256 threads (last one partial)
+// Channel block = 32 NCO output x 32 NCI input channels (NCO, NCI = 1 or 2; LDS rows keep their 128-byte pitch).  The four
+// MFMA waves own the NCO * NCI (co, ci) fragment pairs; with fewer than four pairs they split the tile's 16 pixel rows
+// between them (a wave then streams 16 / parts rows + 2 halo rows and the split-K reduction adds the parts up).
 constexpr int kWrAcc = 9 * 16 * 64;            // accumulator floats per consumer wave (slab layout of the two-stage reduction)
 
 template <typename T>
@@ -57,17 +58,23 @@ __device__ __forceinline__ typename Frag16<T>::type wr_tr_read(const char* base0
     return u.v;
 }
 
-template <typename T>
+template <typename T, int NCO, int NCI, bool RAW>
 __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams p = pin_params(p_in);
     constexpr int VEC = 8;
+    constexpr int BCO = 32 * NCO, BCI = 32 * NCI;
+    constexpr int NPAIRS = NCO * NCI, NPARTS = 4 / NPAIRS, RP = 16 / NPARTS;     // fragment pairs, row parts, rows per part
+    // staging: 16-B vectors per thread - dy 256 px x 4 NCO chunks, halo 324 px x 4 NCI chunks over 256 threads
+    constexpr int DYCH = 4 * NCO, XCH = 4 * NCI;
+    constexpr int DYSTEP = 256 / DYCH, XSTEP = 256 / XCH;
+    constexpr int kWrDySlots = DYCH, kWrInSlots = (kWrInRows + XSTEP - 1) / XSTEP;
     typedef typename Frag16<T>::type frag_t;
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool consumer = wave < 4;
 
-    const int ncib = p.Cin / 64;
+    const int ncib = p.Cin / BCI;
     int bx = blockIdx.x, by = blockIdx.y;
     {   // XCD-aware order (conv_wgrad.hip): the channel-block pairs of one k-slice share an L2
         const int G = gridDim.x * gridDim.y;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         }
     }
     const int cib = bx % ncib, cob = bx / ncib;
-    const int co0 = cob * 64, ci0 = cib * 64;
+    const int co0 = cob * BCO, ci0 = cib * BCI;
     const int total_tiles = p.N * p.tiles_y * p.tiles_x;
 
     auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
@@ -106,7 +113,9 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         // is transformed and stored to LDS and the same registers immediately take the load of slot i of tile k+2 - every
         // load has a whole iteration to arrive, whichever slot it is (with all loads issued behind the commit, the next
         // iteration's first use waited for loads that were a barrier old: measured 26 of 95 us).
-        const int pt = t & 255, ch8 = pt & 7, rowp = pt >> 3;         // 16-B chunk of the 128-B row, first pixel row of this thread
+        const int pt = t & 255;
+        const int dch = pt % DYCH, drow = pt / DYCH;                  // dy: 16-B chunk of the row, first pixel of this thread
+        const int xch = pt % XCH, xrow = pt / XCH;                    // halo: the same for the conv input
         // TWO register sets, two tiles ahead: a tile's loads are issued two iterations (~8 us) before its commit.  With one
         // set (one tile = 76 KB per CU in flight) the commit waited for its data every iteration - 19.5 MB in flight
         // chip-wide is ~4 us at the rate the memory system delivers this pattern, longer than a tile's MFMA time.
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
             int ty0, tx0;                  // where the tile lies (edge handling at commit time)
         };
         StageSet S0, S1;
-        const int c_out = co0 + ch8 * VEC, c_in = ci0 + ch8 * VEC;
+        const int c_out = co0 + dch * VEC, c_in = ci0 + xch * VEC;
         // conv input: the 64-channel block lies in ONE concat source (host-checked: src0.C is a multiple of 64) - workgroup-uniform
         const bool w1 = __builtin_amdgcn_readfirstlane((p.nsrc > 1 && ci0 >= p.src[0].C) ? 1 : 0) != 0;
         const int cs = w1 ? c_in - p.src[0].C : c_in;
@@ -137,13 +146,13 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         unsigned rel_dy[kWrDySlots], rel_x[kWrInSlots];
     #pragma unroll
         for (int i = 0; i < kWrDySlots; ++i) {
-            const int px = rowp + 32 * i;
+            const int px = drow + DYSTEP * i;
             rel_dy[i] = (unsigned)(((px >> 4) * p.W + (px & 15)) * p.Cout + c_out) * 2u;
         }
     #pragma unroll
         for (int i = 0; i < kWrInSlots; ++i) {
-            const int hp = rowp + 32 * i;
-            const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18 for hp < 352
+            const int hp = xrow + XSTEP * i;
+            const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18 for hp < 400
             rel_x[i] = (unsigned)((hy * Ws + hx) * Cs + cs) * 2u;
         }
         auto dy_tile_off = [&](int n, int ty0, int tx0) { return (unsigned)(((n * p.H + ty0) * p.W + tx0) * p.Cout) * 2u; };
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
             for (int i = 0; i < kWrDySlots; ++i) load_slot_dy(S, i, dyo);
     #pragma unroll
             for (int i = 0; i < kWrInSlots; ++i) load_slot_x(S, i, xo);
-            load_aff(S, n);
+            if (!RAW) load_aff(S, n);
             S.ty0 = ty0; S.tx0 = tx0;
         };
         // Stores the tile held by set S into `buf` and refills every slot of S with tile (n, ty0, tx0).  STRAIGHT-LINE on
@@ -181,8 +190,8 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         auto commit_issue = [&](StageSet& S, char* buf, int n, int ty0, int tx0) {
             char* lds_dy = buf;
             char* lds_in = buf + kWrDyBytes;
-            int rq = rowp;
-            asm volatile("" : "+v"(rq));
+            int dq = drow, xq = xrow;
+            asm volatile("" : "+v"(dq), "+v"(xq));      // slot rows are recomputed, not kept live
             const unsigned dyo = dy_tile_off(n, ty0, tx0), xo = x_tile_off(n, ty0, tx0);
             const int pty0 = S.ty0, ptx0 = S.tx0;
             float sc[VEC], sh[VEC];
@@ -190,25 +199,28 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
             for (int e = 0; e < VEC; ++e) { sc[e] = S.sc[e]; sh[e] = S.sh[e]; }
     #pragma unroll
             for (int i = 0; i < kWrDySlots; ++i) {
-                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(S.dy[i].v)*>(lds_dy + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = S.dy[i].v;
+                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(S.dy[i].v)*>(lds_dy + lds_off128(dq + DYSTEP * i, dch >> 2, dch & 3)) = S.dy[i].v;
                 else asm volatile("" ::"v"(S.dy[i].v));
                 load_slot_dy(S, i, dyo);
             }
     #pragma unroll
             for (int i = 0; i < kWrInSlots; ++i) {
                 Vec16<T> v = S.x[i];
-                if (!(MRISR_WR_DBG & 2)) {
+                if (!RAW && !(MRISR_WR_DBG & 2)) {      // (sources stored as-is - pooled / up-sampled / blended inputs - go to LDS as loaded)
     #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const float y = fmaf(v.get(e), sc[e], sh[e]);
                         v.set(e, fmaxf(y, slope * y));
                     }
                 }
-                if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128(rq + 32 * i, ch8 >> 2, ch8 & 3)) = v.v;
-                else asm volatile("" ::"v"(v.v));
+                // (rows 324 .. of the last slot are never read; the image holds 352 rows)
+                if (i < kWrInSlots - 1 || xq + XSTEP * i < 352) {
+                    if (!(MRISR_WR_DBG & 8)) *reinterpret_cast<decltype(v.v)*>(lds_in + lds_off128(xq + XSTEP * i, xch >> 2, xch & 3)) = v.v;
+                    else asm volatile("" ::"v"(v.v));
+                }
                 load_slot_x(S, i, xo);
             }
-            load_aff(S, n);
+            if (!RAW) load_aff(S, n);
             S.ty0 = ty0; S.tx0 = tx0;
             // edge tiles: zeros over the slots that lie outside the plane / the source (conv padding, partial tiles)
             const int ys0 = pty0 - 1 - offy, xs0 = ptx0 - 1 - offx;
@@ -218,17 +230,17 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
                 z.zero();
     #pragma unroll
                 for (int i = 0; i < kWrDySlots; ++i) {
-                    const int px = rq + 32 * i;
+                    const int px = dq + DYSTEP * i;
                     if (!(pty0 + (px >> 4) < p.H && ptx0 + (px & 15) < p.W))
-                        *reinterpret_cast<decltype(z.v)*>(lds_dy + lds_off128(px, ch8 >> 2, ch8 & 3)) = z.v;
+                        *reinterpret_cast<decltype(z.v)*>(lds_dy + lds_off128(px, dch >> 2, dch & 3)) = z.v;
                 }
     #pragma unroll
                 for (int i = 0; i < kWrInSlots; ++i) {
-                    const int hp = rq + 32 * i;
+                    const int hp = xq + XSTEP * i;
                     const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
                     const unsigned y = ys0 + hy, x = xs0 + hx;
-                    if (!(y < (unsigned)Hs && x < (unsigned)Ws))      // (rows 324 .. 351 of the last slot are never read)
-                        *reinterpret_cast<decltype(z.v)*>(lds_in + lds_off128(hp, ch8 >> 2, ch8 & 3)) = z.v;
+                    if (hp < kWrInRows && !(y < (unsigned)Hs && x < (unsigned)Ws))
+                        *reinterpret_cast<decltype(z.v)*>(lds_in + lds_off128(hp, xch >> 2, xch & 3)) = z.v;
                 }
             }
         };
@@ -275,7 +287,8 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
     }
 
     // ------------------------------------------------------------------ consumer state (waves 0-3): fragment pair (fo, fi)
-    const int fo = (wave >> 1) & 1, fi = wave & 1;
+    const int pair = wave % NPAIRS, rpart = wave / NPAIRS;      // fragment pair and row part of this wave
+    const int fo = pair / NCI, fi = pair % NCI;
     f32x16 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i)
@@ -306,22 +319,28 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         };
         // A: ring of four pixel rows (row y is used by halo rows y .. y + 2 while row y + 1 ... y + 3 arrive), B: two sets of
         // three column shifts; everything for halo row h + 1 is requested before the MFMAs of halo row h are issued
+        // this wave's rows: pixel rows r0 .. r0 + RP - 1, halo rows r0 .. r0 + RP + 1 (r0 * 18 is a multiple of 4: the
+        // swizzle class of K = h * 18 + kx depends on the row INSIDE the part only)
+        const int r0 = rpart * RP;
+        ab += r0 * 2048;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bb[j] += r0 * 18 * 128;
         frag_t A[4], B[2][3];
         A[0] = load_a(0);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) B[0][kx] = load_b(0, kx);
 #pragma unroll
-        for (int h = 0; h < 18; ++h) {
-            if (h + 1 < 18) {
+        for (int h = 0; h < RP + 2; ++h) {
+            if (h + 1 < RP + 2) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) B[(h + 1) & 1][kx] = load_b(h + 1, kx);
-                if (h + 1 < 16) A[(h + 1) & 3] = load_a(h + 1);
+                if (h + 1 < RP) A[(h + 1) & 3] = load_a(h + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int y = h - ky;
-                if (y >= 0 && y < 16) {
+                if (y >= 0 && y < RP) {
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         if (MRISR_WR_DBG & 1) asm volatile("" ::"v"(A[y & 3]), "v"(B[h & 1][kx]));
@@ -367,10 +386,11 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         }
 }
 
-// Second stage: dw[co][tap][ci] += sum over the split-K slabs (thread = one accumulator element of the slab layout)
+// Second stage: dw[co][tap][ci] += sum over the split-K slabs (thread = one accumulator element of the slab layout; the row
+// parts of one fragment pair land on the same element of dw)
 constexpr int kWrRedChunk = 8;
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
-                                                                int ksplit, int Cout, int Cin) {
+                                                                int ksplit, int Cout, int Cin, int nco, int nci) {
     const int per_blk = 4 * kWrAcc;
     const size_t total = (size_t)nblk * per_blk;
     const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -383,9 +403,9 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __r
     const int blk = idx / per_blk, rem = idx - (size_t)blk * per_blk;
     const int wave = rem / kWrAcc, ar = (rem - wave * kWrAcc) >> 6, lane = rem & 63;
     const int a = ar >> 4, r = ar & 15, lr = lane & 31, lh = lane >> 5;
-    const int ncib = Cin / 64, cib = blk % ncib, cob = blk / ncib;
-    const int fo = (wave >> 1) & 1, fi = wave & 1;
-    const int co = cob * 64 + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ci = cib * 64 + fi * 32 + lr;
+    const int ncib = Cin / (32 * nci), cib = blk % ncib, cob = blk / ncib;
+    const int pair = wave % (nco * nci), fo = pair / nci, fi = pair % nci;
+    const int co = cob * 32 * nco + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ci = cib * 32 * nci + fi * 32 + lr;
     if (s != 0.f) atomic_add_f32(dw + ((size_t)co * 9 + a) * Cin + ci, s);
 }
 
@@ -408,15 +428,17 @@ bool conv_wgrad_rows_ok(const mrisr_conv_desc* d) {
 #endif
     if (d->dtype != MRISR_BF16 && d->dtype != MRISR_F16) return false;
     if (d->ksize != 3 || d->combine != MRISR_COMBINE_CONCAT) return false;
-    if (d->Cout % 64 || d->Cin % 64 || d->H < 16 || d->W < 16) return false;
+    if (d->Cout % 32 || d->Cin % 32 || d->H < 16 || d->W < 16) return false;
     for (int s = 0; s < d->nsrc; ++s)
         if (d->src[s].spatial != MRISR_SP_NONE) return false;
-    if (d->nsrc > 1 && d->src[0].C % 64) return false;
+    const int bci = d->Cin % 64 ? 32 : 64;
+    if (d->nsrc > 1 && d->src[0].C % bci) return false;      // an input-channel block lies in one concat source
     return true;
 }
 
 static void wgrad_rows_grid(const ConvParams& p, int& nblk, int& ksplit, int& total_tiles) {
-    nblk = (p.Cout / 64) * (p.Cin / 64);
+    const int bco = p.Cout % 64 ? 32 : 64, bci = p.Cin % 64 ? 32 : 64;
+    nblk = (p.Cout / bco) * (p.Cin / bci);
     total_tiles = p.N * ceil_div(p.H, 16) * ceil_div(p.W, 16);
     ksplit = ceil_div(p.cus > 0 ? p.cus : num_cus(), nblk);
     if (ksplit > total_tiles) ksplit = total_tiles;
@@ -430,7 +452,7 @@ size_t conv_wgrad_rows_workspace_floats(const ConvParams& p) {
     return (size_t)nblk * ksplit * 4 * kWrAcc;
 }
 
-template <typename T>
+template <typename T, int NCO, int NCI>
 static int launch_wgrad_rows_t(ConvParams& p, size_t ws_floats, hipStream_t s) {
     p.th = 16; p.tw_log2 = 4;
     p.tiles_x = ceil_div(p.W, 16); p.tiles_y = ceil_div(p.H, 16);
@@ -439,22 +461,35 @@ static int launch_wgrad_rows_t(ConvParams& p, size_t ws_floats, hipStream_t s) {
     const size_t need = (size_t)nblk * ksplit * 4 * kWrAcc;
     if (!(p.wsp && ksplit >= 4 && need <= ws_floats)) p.wsp = nullptr;
     const size_t lds = 2 * (size_t)kWrBuf;
+    bool raw = true;      // every source stored as-is (pooled / up-sampled / blended inputs): no GroupNorm arithmetic in the staging
+    for (int i = 0; i < p.nsrc; ++i) raw = raw && p.src[i].mode == MRISR_SRC_RAW;
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<T, NCO, NCI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel<T, NCO, NCI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL((conv_wgrad_rows_kernel<T>), dim3(nblk, ksplit), dim3(kWrThreads), lds, s, p);
+    if (raw) hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCO, NCI, true>), dim3(nblk, ksplit), dim3(kWrThreads), lds, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_rows_kernel<T, NCO, NCI, false>), dim3(nblk, ksplit), dim3(kWrThreads), lds, s, p);
     MRISR_CHECK_LAUNCH("conv_wgrad(rows)");
     if (p.wsp) {
         const size_t total = need / ksplit;
-        wgrad_rows_reduce_kernel<<<dim3((unsigned)((total + 255) / 256), ceil_div(ksplit, kWrRedChunk)), 256, 0, s>>>(p.wsp, p.dw, nblk, ksplit, p.Cout, p.Cin);
+        wgrad_rows_reduce_kernel<<<dim3((unsigned)((total + 255) / 256), ceil_div(ksplit, kWrRedChunk)), 256, 0, s>>>(p.wsp, p.dw, nblk, ksplit, p.Cout, p.Cin, NCO, NCI);
         MRISR_CHECK_LAUNCH("conv_wgrad(rows reduce)");
     }
     return MRISR_OK;
 }
 
+template <typename T>
+static int launch_wgrad_rows_d(ConvParams& p, size_t ws_floats, hipStream_t s) {
+    const bool co2 = p.Cout % 64 == 0, ci2 = p.Cin % 64 == 0;
+    if (co2 && ci2) return launch_wgrad_rows_t<T, 2, 2>(p, ws_floats, s);
+    if (co2) return launch_wgrad_rows_t<T, 2, 1>(p, ws_floats, s);
+    if (ci2) return launch_wgrad_rows_t<T, 1, 2>(p, ws_floats, s);
+    return launch_wgrad_rows_t<T, 1, 1>(p, ws_floats, s);
+}
+
 int launch_wgrad_rows(int dtype, ConvParams& p, size_t ws_floats, hipStream_t s) {
-    if (dtype == MRISR_BF16) return launch_wgrad_rows_t<bf16_t>(p, ws_floats, s);
-    return launch_wgrad_rows_t<f16_t>(p, ws_floats, s);
+    if (dtype == MRISR_BF16) return launch_wgrad_rows_d<bf16_t>(p, ws_floats, s);
+    return launch_wgrad_rows_d<f16_t>(p, ws_floats, s);
 }
 #endif

@@ -256,13 +256,15 @@ def test_conv_wgrad(dt, case, use_ws):
 # ------------------------------------------------------------------------------------------- stem / head
 @pytest.mark.parametrize("dt", [L.BF16, L.F16])
 @pytest.mark.parametrize("use_ws", [False, True])
-@pytest.mark.parametrize("case", ["norm_edges", "raw_wide", "concat_pad", "deep_small"])
+@pytest.mark.parametrize("case", ["norm_edges", "raw_wide", "concat_pad", "deep_small", "narrow_raw_32x32", "narrow_64to32",
+                                  "narrow_32to64_norm"])
 def test_conv_wgrad_rows(dt, case, use_ws):
     """csrc/conv_wgrad_rows.hip (row-streaming weight gradient with producer / consumer waves): 16-bit, 3x3, Cout and Cin
     multiples of 64, planes >= 16 x 16.  norm_edges: GroupNorm source, plane sizes that are no multiples of the 16 x 16
     tile, several tiles per workgroup; raw_wide: a stored source, 2 x 1 channel blocks; concat_pad: two GroupNorm sources
     of 64 channels each, the second smaller than the conv input and offset (unet_model.py:86-93); deep_small: 256 -> 128
-    channels on 16 x 16 planes (one tile per image, 8 channel-block pairs)."""
+    channels on 16 x 16 planes (one tile per image, 8 channel-block pairs); narrow_*: 32-channel blocks (row-split MFMA
+    waves), stored and GroupNorm sources."""
     if case == "norm_edges":
         n, cin, cout, h, w = 3, 64, 128, 40, 72
         srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=70), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 71))]
@@ -273,9 +275,18 @@ def test_conv_wgrad_rows(dt, case, use_ws):
         n, cin, cout, h, w = 2, 128, 64, 33, 35
         srcs = [U.SrcSpec(rnd(n, 64, h, w, seed=73), L.SRC_NORM, L.SP_NONE, *gn_affine(n, 64, 74)),
                 U.SrcSpec(rnd(n, 64, 32, 33, seed=75), L.SRC_NORM, L.SP_NONE, *gn_affine(n, 64, 76), off=(0, 1))]
-    else:
+    elif case == "deep_small":
         n, cin, cout, h, w = 4, 256, 128, 16, 16
         srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=77), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 78))]
+    elif case == "narrow_raw_32x32":      # one fragment pair: the four MFMA waves split the tile's rows four ways (final_conv.0)
+        n, cin, cout, h, w = 2, 32, 32, 40, 56
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=80))]
+    elif case == "narrow_64to32":         # two pairs, two row parts (final_up_bilinear.1: a stored, up-sampled input)
+        n, cin, cout, h, w = 2, 64, 32, 33, 48
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=81))]
+    else:
+        n, cin, cout, h, w = 2, 32, 64, 24, 40
+        srcs = [U.SrcSpec(rnd(n, cin, h, w, seed=82), L.SRC_NORM, L.SP_NONE, *gn_affine(n, cin, 83))]
     dy = rnd(n, cout, h, w, seed=79)
     ran = []
     dw = U.conv_wgrad(dt, srcs, dy, cout, cin, h, w, 3, use_ws=use_ws, variant=ran)
