@@ -49,11 +49,10 @@ static inline int conv_wgrad_fast(int dtype, int loader, int ks, int tw_log2, in
     if (!nfo || !nfi) return 0;
     return 4 / (nfo * nfi);
 }
-// output-channel block of the ring weight layout (csrc/conv_ring.hip) for an operand, 0 = that kernel does not take it
+// output-channel block of the ring weight layout (csrc/conv_ring.hip, csrc/conv_pc.hip) for an operand, 0 = no such image
 __host__ __device__ static inline int conv_ring_bn(int dtype, int Cout, int Cin, int ksize) {
     if (dtype != MRISR_BF16 && dtype != MRISR_F16) return 0;
     if (ksize != 3 || Cin % 16 || Cout % 128) return 0;
-    if (Cin < 256) return 0;      // the ring pays from 256 input channels on (profiles/r03_ring_kernel.txt): no image for the others
     return 128;
 }
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }

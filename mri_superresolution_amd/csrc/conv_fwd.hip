@@ -1375,6 +1375,9 @@ int launch_gn_stats(int dtype, const void* x, double* stats, int N, int HW, int 
 bool conv_ring_eligible(const mrisr_conv_desc* d, const ConvParams& p);
 bool conv_wgrad_rows_ok(const mrisr_conv_desc* d);
 int launch_conv_ring(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
+// conv_pc.hip: producer / consumer waves (GroupNorm or stored sources, 128-channel output blocks)
+bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p);
+int launch_conv_pc(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
 
 // every source stored as-is and a plain (single / concat) loader: the halo tile can go global -> LDS by LDS-DMA
 static bool conv_dma_halo(const ConvParams& p, int spatial) {
@@ -1485,6 +1488,8 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
                  conv_wgrad_fast(d->dtype, loader, d->ksize, p.tw_log2, d->Cout, d->Cin));
     } else if (conv_ring_eligible(d, p)) {
         snprintf(out, n, "conv_ring_kernel<%s,2,4>", t);
+    } else if (conv_pc_eligible(d, p)) {
+        snprintf(out, n, "conv_pc_kernel<%s,%d>", t, d->src[0].mode == MRISR_SRC_NORM ? 1 : 0);
     } else {
         const int BN = conv_choose_bn(d->Cout);
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
@@ -1506,6 +1511,7 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
         MRISR_FAIL(MRISR_E_UNSUPPORTED, "conv_forward: relu_mask needs a plain output with Cout a multiple of the 16-byte vector");
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);
     if (conv_ring_eligible(d, p)) return launch_conv_ring(d, p, (hipStream_t)stream);
+    if (conv_pc_eligible(d, p)) return launch_conv_pc(d, p, (hipStream_t)stream);
     // square 16 x 16 output tiles (324-pixel halo, 18-pixel rows) instead of 8 x 32 (340, 34): the kernels are bound by the
     // operand bytes they stage (profiles/NOTES.md R2-13/14).  32 -> 32 at 512^2: 167 -> 130 us, 64 -> 32 / 32 -> 64: 3-5 %, wide
     // layers +-2 % each, the training step -0.8 % with every 3x3 layer on 16 x 16 (A/B on one box).  The weight-gradient

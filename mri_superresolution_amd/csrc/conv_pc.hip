@@ -1,0 +1,480 @@
+// 3x3 convolution on MFMA with PRODUCER / CONSUMER waves (gfx950): forward of the GroupNorm-sourced layers and the layers /
+// input gradients with stored sources whose output has a multiple of 128 channels.
+//
+// Replaces the same aten conv2d / convolution_backward(input) calls as conv_fwd.hip
+// (/root/reference/models/unet_model.py:29,34,152,168 and autograd's dgrad of them).
+//
+// Why a third forward kernel (profiles/NOTES.md R3-2 .. R3-5): in conv_igemm_kernel all eight waves of a workgroup load,
+// GroupNorm+LeakyReLU-transform and LDS-store the next chunk BETWEEN their MFMAs - ~36 vector instructions per 16-byte
+// vector at ~7 cycles each beside the other wave's MFMAs - and every wave waits at two barriers per chunk.  The
+// weight-gradient kernel conv_wgrad_rows.hip showed what the split into roles buys: an MFMA-only wave per SIMD runs at
+// 38 cycles per MFMA (84 % of the pipe) as long as the staging waves keep up.  The same split here:
+//   * waves 0-3 (one per SIMD, the older ones: they win the issue arbitration) only read fragments and issue MFMAs: a wave
+//     owns 64 pixels x 128 output channels (128 accumulator registers, 6 fragment reads per 8 MFMAs), runs its tile's
+//     epilogue (GroupNorm statistics, 16-byte stores) itself;
+//   * waves 4-7 only stage: buffer loads of the item after next into registers (halo tile 10 x 34 pixels x 16 channels and
+//     the item's 36-KiB weight image), GroupNorm + LeakyReLU on the halo vectors that have arrived, LDS stores.
+// Work item = 8 x 32 pixels x 128 output channels x 16 input channels (32-byte LDS rows, the ring kernel's layouts: the
+// weight image is the ring-packed one, [cout block][cin chunk][tap][128 rows][32 B], slots pre-swizzled).  Two LDS
+// buffers + two register sets: an item's loads are issued two items (~3 us) before its commit.  One barrier per item.
+#include <mutex>
+#include <type_traits>
+
+#include "conv_common.h"
+
+// Ablation switches of tuning builds (tools/build_src_variant.sh; results invalid by construction, timing only):
+// 1 no MFMA, 2 no GroupNorm / LeakyReLU transform, 4 no epilogue.  0 in the product library.
+#ifndef MRISR_PC_DBG
+#define MRISR_PC_DBG 0
+#endif
+// Phase profile (tuning builds only, -DMRISR_PC_PT; tools/conv_bench.py prints it): slot 6 = work, 5 = barrier wait,
+// 4 = epilogue, 10 = 100 MHz ticks of the loop.
+#ifdef MRISR_PC_PT
+__device__ unsigned long long g_pc_cycles[8][12];
+#define PPT_DECL unsigned long long pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime(); const unsigned long long pt_r0 = __builtin_amdgcn_s_memrealtime();
+#define PPT_MARK(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_now - pt_t; pt_t = pt_now; __builtin_amdgcn_sched_barrier(0); }
+#define PPT_DUMP() if (blockIdx.x == gridDim.x / 2 && lane == 0) { pt_acc[10] = __builtin_amdgcn_s_memrealtime() - pt_r0; for (int k = 0; k < 12; ++k) atomicAdd(&g_pc_cycles[wave][k], pt_acc[k]); if (threadIdx.x == 0) atomicAdd(&g_pc_cycles[0][11], 1ull); }
+#else
+#define PPT_DECL
+#define PPT_MARK(k)
+#define PPT_DUMP()
+#endif
+#ifndef MRISR_PC_AD
+#define MRISR_PC_AD 3        // weight-fragment prefetch distance (fragments)
+#endif
+
+constexpr int kPcThreads = 512;
+constexpr int kPcBN = 128;                       // output channels per workgroup
+constexpr int kPcHaloW = 34, kPcHaloH = 10, kPcHaloRows = kPcHaloW * kPcHaloH;     // 8 x 32 pixel tile + halo
+constexpr int kPcHaloSlots = 3;                  // 16-byte vectors per staging thread: 256 x 3 >= 340 rows x 2
+constexpr int kPcHaloBytes = 256 * kPcHaloSlots * 16;        // (the last slot stores unpredicated: 768 vectors of room)
+constexpr int kPcWBytes = 9 * kPcBN * 32;        // weight image of one (cout block, cin chunk)
+constexpr int kPcWSlots = kPcWBytes / (256 * 16);
+constexpr int kPcBuf = kPcHaloBytes + kPcWBytes;
+static_assert(kPcWSlots * 256 * 16 == kPcWBytes, "whole slots");
+
+template <typename T, bool NORM, bool STATS>
+__global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams p_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams p = pin_params(p_in);
+    typedef typename Frag16<T>::type frag_t;
+    constexpr int MI = 2, NI = 4, BN = kPcBN, VEC = 8;
+    const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool consumer = wave < 4;
+    float* lds_bias = reinterpret_cast<float*>(smem + 2 * kPcBuf);
+
+    // XCD-aware workgroup order (conv_fwd.hip): the cout blocks of a tile range, then the neighbouring ranges, share an L2
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int cb = bid % p.ncb;
+    const int bt0 = (bid / p.ncb) * p.tiles_per_block;
+    const int bt1 = min(bt0 + p.tiles_per_block, p.ntiles);
+    const int total = max(bt1 - bt0, 0) * p.nchunks;     // items of this workgroup
+    const int bn0 = cb * BN;
+    if (total <= 0) return;
+    if (t < BN) lds_bias[t] = p.bias ? gload<float>(p.bias + bn0 + t) : 0.f;
+
+    auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
+        const int tx = tile % p.tiles_x;
+        const int r = tile / p.tiles_x;
+        n = r / p.tiles_y;
+        ty0 = (r - n * p.tiles_y) * 8;
+        tx0 = tx * 32;
+    };
+
+    // ------------------------------------------------------------------ schedule: one barrier per item
+    //   consumers:  MFMA(item k) from buffer k & 1 (+ the tile's epilogue behind its last item)
+    //   producers:  commit(item k+1) into buffer (k+1) & 1  ->  issue loads(item k+3) into the registers just freed
+    // Two separate loops with the same barrier sequence: neither role's registers are live in the other's code.
+    if (!consumer) {
+        // ------------------------------------------------------------------ producer (waves 4-7): 256 staging threads
+        const int pt = t & 255;
+        // halo vector v = pt + 256 j lies at LDS byte 16 v: row v >> 1 = (pt >> 1) + 128 j, physical slot pt & 1, which holds
+        // the LOGICAL 8-channel half (pt & 1) ^ ((row >> 3) & 1) = (pt & 1) ^ ((pt >> 4) & 1)
+        const int hrow0 = pt >> 1;
+        const int lslot = (pt & 1) ^ ((pt >> 4) & 1);
+        struct StageSet {
+            Vec16<T> h[kPcHaloSlots];
+            u32x4 w[kPcWSlots];
+            float sc[VEC], sh[VEC];
+            int ty0, tx0, w1;
+        };
+        StageSet S0, S1;
+        // per-source geometry (concat: a 16-channel chunk lies in ONE source - host-checked src0.C % 16 == 0)
+        const int C0 = p.src[0].C;
+        const bool two = p.nsrc > 1;
+        const __amdgpu_buffer_rsrc_t x_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.src[0].ptr), 0, (int)((unsigned)p.N * p.src[0].img_bytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(two ? p.src[1].ptr : p.src[0].ptr), 0, (int)((unsigned)p.N * (two ? p.src[1].img_bytes : p.src[0].img_bytes)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.wpacked), 0, (int)((unsigned)p.ncb * p.nchunks * kPcWBytes), 0x00020000);
+        unsigned rel0[kPcHaloSlots], rel1[kPcHaloSlots];
+#pragma unroll
+        for (int j = 0; j < kPcHaloSlots; ++j) {
+            const int row = hrow0 + 128 * j;
+            const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;        // row / 34 for row < 1000
+            rel0[j] = (unsigned)((hy * p.src[0].W + hx) * p.src[0].C + lslot * VEC) * 2u;
+            rel1[j] = two ? (unsigned)((hy * p.src[1].W + hx) * p.src[1].C + lslot * VEC) * 2u : rel0[j];
+        }
+        const unsigned wv = (unsigned)pt * 16u;
+
+        // Loads of item (tile at n, ty0, tx0; chunk kc) into S.  STRAIGHT-LINE: no branch around a load (conv_wgrad_rows.hip:
+        // with branches hipcc gives up counting and waits for the load it has just issued); the source of a chunk is picked
+        // with scalar selects.  Halo offsets outside the tensor return zeros (hardware range check); halo pixels beside the
+        // plane alias into neighbouring rows and are overwritten with zeros at commit time (edge tiles only).
+        auto issue = [&](StageSet& S, int n, int ty0, int tx0, int kc) {
+            const bool w1 = two && kc * 16 >= C0;
+            const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W, Cs = w1 ? p.src[1].C : C0;
+            const int offy = w1 ? p.src[1].off_y : p.src[0].off_y, offx = w1 ? p.src[1].off_x : p.src[0].off_x;
+            const int cs = kc * 16 - (w1 ? C0 : 0);
+            const unsigned tile_off = (unsigned)(((n * Hs + ty0 - 1 - offy) * Ws + tx0 - 1 - offx) * Cs + cs) * 2u;
+            const __amdgpu_buffer_rsrc_t rs = w1 ? x_rsrc1 : x_rsrc0;
+#pragma unroll
+            for (int j = 0; j < kPcHaloSlots; ++j) {
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tile_off + (w1 ? rel1[j] : rel0[j])), 0, 0);
+                S.h[j].v = __builtin_bit_cast(decltype(S.h[j].v), r);
+            }
+            const int woff = (cb * p.nchunks + kc) * kPcWBytes;
+#pragma unroll
+            for (int j = 0; j < kPcWSlots; ++j)
+                S.w[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(wv + 4096u * j), woff, 0);
+            if (NORM) {
+                const float* scp = (w1 ? p.src[1].scale : p.src[0].scale) + (size_t)n * Cs + cs + lslot * VEC;
+                const float* shp = (w1 ? p.src[1].shift : p.src[0].shift) + (size_t)n * Cs + cs + lslot * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const f32x4 a = gload<f32x4>(scp + e), b = gload<f32x4>(shp + e);
+                    S.sc[e] = a[0]; S.sc[e + 1] = a[1]; S.sc[e + 2] = a[2]; S.sc[e + 3] = a[3];
+                    S.sh[e] = b[0]; S.sh[e + 1] = b[1]; S.sh[e + 2] = b[2]; S.sh[e + 3] = b[3];
+                }
+            }
+            S.ty0 = ty0; S.tx0 = tx0; S.w1 = w1 ? 1 : 0;
+        };
+        PPT_DECL
+        // Stores the item held by S into `buf` (halo transformed), then refills S with item (n, ty0, tx0, kc)
+        auto commit_issue = [&](StageSet& S, char* buf, int n, int ty0, int tx0, int kc) {
+            char* lds_h = buf;
+            char* lds_w = buf + kPcHaloBytes;
+            int q = pt;
+            asm volatile("" : "+v"(q));
+            const int pty0 = S.ty0, ptx0 = S.tx0, pw1 = S.w1;
+#pragma unroll
+            for (int j = 0; j < kPcHaloSlots; ++j) {
+                Vec16<T> v = S.h[j];
+                if (NORM && !(MRISR_PC_DBG & 2)) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float y = fmaf(v.get(e), S.sc[e], S.sh[e]);
+                        v.set(e, fmaxf(y, LRELU_SLOPE * y));
+                    }
+                }
+                *reinterpret_cast<decltype(v.v)*>(lds_h + (q + 256 * j) * 16) = v.v;
+            }
+            PPT_MARK(0)
+#pragma unroll
+            for (int j = 0; j < kPcWSlots; ++j) *reinterpret_cast<u32x4*>(lds_w + (q + 256 * j) * 16) = S.w[j];
+            PPT_MARK(1)
+            issue(S, n, ty0, tx0, kc);
+            PPT_MARK(3)
+            // edge tiles: zeros over the halo pixels outside the source (conv padding)
+            const bool w1 = pw1 != 0;
+            const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W;
+            const int ys0 = pty0 - 1 - (w1 ? p.src[1].off_y : p.src[0].off_y), xs0 = ptx0 - 1 - (w1 ? p.src[1].off_x : p.src[0].off_x);
+            const bool interior = ys0 >= 0 && xs0 >= 0 && ys0 + kPcHaloH <= Hs && xs0 + kPcHaloW <= Ws;
+            if (!interior) {
+                Vec16<T> z;
+                z.zero();
+#pragma unroll
+                for (int j = 0; j < kPcHaloSlots; ++j) {
+                    const int row = (q >> 1) + 128 * j;
+                    const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;
+                    const unsigned y = ys0 + hy, x = xs0 + hx;
+                    if (row < kPcHaloRows && !(y < (unsigned)Hs && x < (unsigned)Ws))
+                        *reinterpret_cast<decltype(z.v)*>(lds_h + (q + 256 * j) * 16) = z.v;
+                }
+            }
+        };
+
+        // item cursor of the loads (runs three items ahead of the MFMAs; past the end it stays on the last item: the tail
+        // re-loads it and stores an image nobody reads)
+        int l_idx = 0, l_tile = bt0, l_kc = 0, ln, lty0, ltx0;
+        decode(l_tile, ln, lty0, ltx0);
+        auto step = [&]() {
+            if (l_idx + 1 < total) {
+                ++l_idx;
+                if (++l_kc == p.nchunks) {
+                    l_kc = 0;
+                    ++l_tile;
+                    decode(l_tile, ln, lty0, ltx0);
+                }
+            }
+        };
+        issue(S0, ln, lty0, ltx0, l_kc);
+        step();
+        issue(S1, ln, lty0, ltx0, l_kc);
+        step();
+        commit_issue(S0, smem, ln, lty0, ltx0, l_kc);
+        step();
+        __syncthreads();
+        PPT_MARK(8)
+        // two items per trip, no exit between them (with a `break` in the middle hipcc's wait-count pass merges the two halves
+        // conservatively: `vmcnt(0)` before the first half's commit, i.e. a wait for the loads issued one barrier ago); an odd
+        // item count is padded with a staging-only half - the consumers run the same number of barriers
+#pragma unroll 1
+        for (int c = 0; c < total; c += 2) {
+            commit_issue(S1, smem + kPcBuf, ln, lty0, ltx0, l_kc);
+            step();
+            PPT_MARK(6)
+            __syncthreads();
+            PPT_MARK(5)
+            commit_issue(S0, smem, ln, lty0, ltx0, l_kc);
+            step();
+            PPT_MARK(6)
+            __syncthreads();
+            PPT_MARK(5)
+        }
+        PPT_DUMP()
+        return;
+    }
+
+    // ------------------------------------------------------------------ consumer (waves 0-3)
+    // weight image rows q = tap*BN + ni*32 + lr, 32 B each, 16-B slot s at position s ^ ((q >> 3) & 1) = s ^ ((lr >> 3) & 1)
+    const int a_off = kPcHaloBytes + lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
+    // halo image rows r = (MI*wave + mi + ky)*34 + kx + lr, slot s at position s ^ ((r >> 3) & 1): one offset per (mi+ky, kx)
+    int xb[(MI + 2) * 3];
+#pragma unroll
+    for (int yy = 0; yy < MI + 2; ++yy)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int r = (MI * wave + yy) * kPcHaloW + kx + lr;
+            xb[yy * 3 + kx] = r * 32 + ((lh ^ ((r >> 3) & 1)) << 4);
+        }
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+    const bool has_br = p.bias != nullptr || p.relu_out != 0;
+    const int gs = p.groups > 0 ? p.Cout / p.groups : 4;
+    // GroupNorm partial sums per lane: a group spans >= 16 channels here (host-checked), i.e. the quad pairs {0,1} and {2,3}
+    // of a fragment each lie in one group
+    constexpr int NSQ = STATS ? 2 : 1;
+    float st_s[NI][NSQ], st_ss[NI][NSQ];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < NSQ; ++q) { st_s[ni][q] = 0.f; st_ss[ni][q] = 0.f; }
+
+    // epilogue of a finished tile (as conv_ring.hip): bias / ReLU, GroupNorm partial sums, packed 16-bit values exchanged
+    // between the lane halves (permlane32) -> 16-byte stores.  Whole tiles only (host-checked): no predication.
+    auto epilogue = [&](int n, int ty0, int tx0) {
+        const size_t e0 = ((size_t)(n * p.H + ty0) * p.W + tx0) * p.Cout + bn0;
+        char* obase = (char*)p.out + e0 * sizeof(T);
+        int lh_e = lh;
+        asm volatile("" : "+v"(lh_e));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int py = MI * wave + mi, px = lr;
+            const unsigned loff = mad_u24(mad_u24(py, p.W, px), p.Cout * 2u, 16u * lh_e);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                if (has_br) {
+                    const float floor_v = p.relu_out ? 0.f : -INFINITY;
+                    const float* bl = lds_bias + 4 * lh_e;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ni * 32 + 8 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ni][mi][4 * q + j] = fmaxf(acc[ni][mi][4 * q + j] + b[j], floor_v);
+                    }
+                }
+                u32x2 packed[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[ni][mi][4 * q + j];
+                        acc[ni][mi][4 * q + j] = 0.f;
+                    }
+                    if (STATS) {
+                        const float qs = (v[0] + v[1]) + (v[2] + v[3]);
+                        const float qq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                        st_s[ni][q >> 1] += qs;
+                        st_ss[ni][q >> 1] += qq;
+                    }
+                    typedef __attribute__((ext_vector_type(4))) T t4_t;
+                    union { t4_t b; u32x2 u; } cv;
+                    cv.b = t4_t{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                    packed[q] = cv.u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    const u32x2 a = packed[q], b = packed[q + 1];
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    gstore(obase + loff + (ni * 32 + 8 * q) * 2, o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto flush_stats = [&](int n) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < NSQ; ++q) {
+                int co = bn0 + ni * 32 + 16 * q + 4 * lh;
+                asm volatile("" : "+v"(co));
+                const float s = half_wave_sum(st_s[ni][q]), ss = half_wave_sum(st_ss[ni][q]);
+                if (lr == 0) {
+                    const int g = co / gs;
+                    double* sp = p.stats + stat_slot_off_id(bid, p.N, p.groups) + ((size_t)n * p.groups + g) * 2;
+                    atomic_add_f64(sp, (double)s);
+                    atomic_add_f64(sp + 1, (double)ss);
+                }
+                st_s[ni][q] = 0.f;
+                st_ss[ni][q] = 0.f;
+            }
+    };
+
+    int tile = bt0, kc = 0, n, ty0, tx0;
+    decode(tile, n, ty0, tx0);
+    __syncthreads();
+    PPT_DECL
+    const int total2 = (total + 1) & ~1;       // (the staging loop runs two items per trip)
+#pragma unroll 1
+    for (int c = 0; c < total2; ++c) {
+        if (c >= total) {
+            __syncthreads();
+            break;
+        }
+        const char* buf = smem + (c & 1) * kPcBuf;
+        const char* wl = buf + a_off;
+        // Fragment pipeline (conv_ring.hip): pixel fragments of tap t+1 and weight fragments up to AD steps ahead are requested
+        // before the MFMAs that use the current ones are issued
+        constexpr int AD = MRISR_PC_AD;
+        frag_t af[AD + 1], bf[2][MI];
+        auto load_b = [&](int tap, int set) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) bf[set][mi] = *reinterpret_cast<const frag_t*>(buf + xb[(mi + ky) * 3 + kx]);
+        };
+        auto load_a = [&](int idx) {      // idx = tap * NI + ni
+            af[idx % (AD + 1)] = *reinterpret_cast<const frag_t*>(wl + ((idx / NI) * BN + (idx % NI) * 32) * 32);
+        };
+        load_b(0, 0);
+#pragma unroll
+        for (int i = 0; i < AD; ++i) load_a(i);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int idx = tap * NI + ni;
+                if (idx + AD < 9 * NI) load_a(idx + AD);
+                if (ni == 0 && tap + 1 < 9) load_b(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if (MRISR_PC_DBG & 1) asm volatile("" ::"v"(af[idx % (AD + 1)]), "v"(bf[tap & 1][mi]));
+                    else acc[ni][mi] = Frag16<T>::mma(af[idx % (AD + 1)], bf[tap & 1][mi], acc[ni][mi]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        PPT_MARK(6)
+        if (++kc == p.nchunks) {
+            if (!(MRISR_PC_DBG & 4)) epilogue(n, ty0, tx0);
+            const int n_prev = n;
+            kc = 0;
+            ++tile;
+            if (tile < bt1) decode(tile, n, ty0, tx0);
+            if (STATS && (tile >= bt1 || n != n_prev)) flush_stats(n_prev);
+            PPT_MARK(4)
+        }
+        __syncthreads();
+        PPT_MARK(5)
+    }
+    PPT_DUMP()
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#ifndef MRISR_KERNEL_ONLY
+#ifdef MRISR_PC_PT
+extern "C" int mrisr_debug_phase_reset() {
+    static unsigned long long zeros[96];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pc_cycles), zeros, sizeof(zeros));
+}
+extern "C" int mrisr_debug_phase_cycles(unsigned long long* out96) {
+    return (int)hipMemcpyFromSymbol(out96, HIP_SYMBOL(g_pc_cycles), sizeof(unsigned long long) * 96);
+}
+#endif
+
+// Does this launch take the producer / consumer kernel?  (p: filled by conv_fill_params.)
+bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p) {
+#ifdef MRISR_NO_PC
+    return false;
+#endif
+    if (!d->wpacked_ring) return false;
+    if (d->dtype == MRISR_F32 || d->ksize != 3 || d->Cin % 16 || d->Cout % kPcBN) return false;
+    if (d->out_mode != MRISR_OUT_PLAIN || d->relu_mask || d->combine != MRISR_COMBINE_CONCAT) return false;
+    if (d->nsrc < 1 || d->nsrc > 2) return false;
+    for (int i = 0; i < d->nsrc; ++i) {
+        if (d->src[i].spatial != MRISR_SP_NONE) return false;
+        if (d->src[i].mode != d->src[0].mode) return false;
+        if (d->src[i].mode != MRISR_SRC_NORM && d->src[i].mode != MRISR_SRC_RAW) return false;
+    }
+    if (d->nsrc == 2 && (d->src[0].C % 16)) return false;           // a 16-channel chunk lies in one source
+    // stored sources: the LDS-DMA kernels stage them without any vector work; this kernel wins from 128 input channels on
+    // (8 items per tile epilogue; 128 -> 64 input gradient at 256^2: 171 vs 162 us)
+    if (d->src[0].mode == MRISR_SRC_RAW && d->Cin < 128) return false;
+    for (int i = 0; i < d->nsrc; ++i)                               // 32-bit byte offsets into each source (buffer loads)
+        if ((unsigned long long)d->N * d->src[i].H * d->src[i].W * d->src[i].C * 2ull >= (1ull << 31)) return false;
+    if (d->stats && ((d->Cout / d->groups) & 15)) return false;     // a GroupNorm group spans whole 16-channel quad pairs
+    if (d->H % 8 || d->W % 32) return false;                        // whole 8 x 32 tiles only (unpredicated stores)
+    const int tiles = d->N * (d->H / 8) * (d->W / 32);
+    const int ncb = d->Cout / kPcBN;
+    return (long)tiles * ncb * 4 >= (long)p.cus * 3;                // >= 0.75 work items per CU
+}
+
+template <typename T>
+static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s) {
+    ConvParams p = cp;
+    p.wpacked = d->wpacked_ring;
+    p.nchunks = d->Cin / 16; p.ncb = d->Cout / kPcBN;
+    p.tiles_x = d->W / 32; p.tiles_y = d->H / 8;
+    p.ntiles = d->N * p.tiles_x * p.tiles_y;
+    p.groups = d->stats ? d->groups : 0;
+    int per_cb = cp.cus / p.ncb;
+    if (per_cb < 1) per_cb = 1;
+    if (per_cb > p.ntiles) per_cb = p.ntiles;
+    p.tiles_per_block = ceil_div(p.ntiles, per_cb);
+    per_cb = ceil_div(p.ntiles, p.tiles_per_block);
+    const int grid = per_cb * p.ncb;
+    const size_t lds = 2 * kPcBuf + kPcBN * sizeof(float);
+    const bool norm = d->src[0].mode == MRISR_SRC_NORM, stats = d->stats != nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (norm && stats) hipLaunchKernelGGL((conv_pc_kernel<T, true, true>), dim3(grid), dim3(kPcThreads), lds, s, p);
+    else if (norm) hipLaunchKernelGGL((conv_pc_kernel<T, true, false>), dim3(grid), dim3(kPcThreads), lds, s, p);
+    else if (stats) hipLaunchKernelGGL((conv_pc_kernel<T, false, true>), dim3(grid), dim3(kPcThreads), lds, s, p);
+    else hipLaunchKernelGGL((conv_pc_kernel<T, false, false>), dim3(grid), dim3(kPcThreads), lds, s, p);
+    MRISR_CHECK_LAUNCH("conv_forward(pc)");
+    return MRISR_OK;
+}
+
+int launch_conv_pc(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s) {
+    if (d->dtype == MRISR_BF16) return launch_pc_t<bf16_t>(d, cp, s);
+    return launch_pc_t<f16_t>(d, cp, s);
+}
+#endif

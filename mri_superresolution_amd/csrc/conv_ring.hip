@@ -455,12 +455,13 @@ bool conv_ring_eligible(const mrisr_conv_desc* d, const ConvParams& p) {
 #endif
     if (!d->wpacked_ring) return false;
     if (!mrisr_conv_ring_bn(d->dtype, d->Cout, d->Cin, d->ksize)) return false;
+    if (d->Cin < 256) return false;      // the ring pays from 256 input channels on (profiles/r03_ring_kernel.txt)
     if (d->out_mode != MRISR_OUT_PLAIN || d->relu_mask || d->combine != MRISR_COMBINE_CONCAT) return false;
     if (d->nsrc != 1 || d->src[0].mode != MRISR_SRC_RAW || d->src[0].spatial != MRISR_SP_NONE) return false;
     if (d->stats && ((d->Cout / d->groups) & 15)) return false;     // a GroupNorm group spans whole 16-channel quad pairs
     if (d->H % 16 || d->W % 32) return false;               // whole 16 x 32 tiles only (unpredicated stores, counted waits)
     // (a tile's epilogue - 16 scattered 1-KiB stores per wave, ~4-8 k cycles, both waves of a SIMD at once - is amortised over
-    // Cin / 16 items: measured per layer, the ring wins from 256 input channels on; conv_ring_bn() holds that rule)
+    // Cin / 16 items: measured per layer, the ring wins from 256 input channels on)
     const int tiles = d->N * ceil_div(d->H, 16) * ceil_div(d->W, 32);
     const int ncb = d->Cout / 128;
     return (long)tiles * ncb * 4 >= (long)p.cus * 3;       // >= 0.75 work items per CU

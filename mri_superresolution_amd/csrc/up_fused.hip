@@ -192,7 +192,8 @@ extern "C" int mrisr_up_conv1x1_fused(int dtype, const void* x, const float* sca
     if (!x || !scale || !shift || !wpacked || !z) MRISR_FAIL(MRISR_E_ARG, "up_conv1x1_fused: null pointer");
     if (dtype != MRISR_BF16 && dtype != MRISR_F16) MRISR_FAIL(MRISR_E_DTYPE, "up_conv1x1_fused: 16-bit storage only (dtype %d)", dtype);
     if (N <= 0 || h <= 0 || w <= 0 || Cin % 32 || Cout % 64) MRISR_FAIL(MRISR_E_SHAPE, "up_conv1x1_fused: N%d h%d w%d Cin%d Cout%d", N, h, w, Cin, Cout);
-    if (stats && (groups <= 0 || Cout % groups || (Cout / groups) % 8 || 64 % (Cout / groups) || 64 / (Cout / groups) > 8))
+    // a group is 8 .. 64 channels dividing a 64-channel block, or a whole number of blocks
+    if (stats && (groups <= 0 || Cout % groups || (Cout / groups) % 8 || (64 % (Cout / groups) && (Cout / groups) % 64)))
         MRISR_FAIL(MRISR_E_SHAPE, "up_conv1x1_fused: groups %d for Cout %d", groups, Cout);
     if ((size_t)N * 4 * h * w * Cout >= (1ull << 31)) MRISR_FAIL(MRISR_E_SHAPE, "up_conv1x1_fused: output exceeds 2^31 elements");
     UpParams p{x, scale, shift, wpacked, z, stats, N, h, w, Cin, Cout, stats ? groups : 0, Cin / 32, ceil_div(2 * w, 16), ceil_div(2 * h, 16)};

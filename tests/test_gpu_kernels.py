@@ -143,6 +143,58 @@ def test_conv_ring_raw_source(dt, case):
     assert U.relerr(out, out2) <= TOL_OUT[dt]
 
 
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("case", ["norm", "norm_multi_tile", "norm_concat_pad", "raw_bias_relu", "raw_odd_items", "half_chip"])
+def test_conv_pc_producer_consumer(dt, case):
+    """csrc/conv_pc.hip (staging waves + MFMA waves, 8 x 32 x 128-channel items of 16 input channels): launches that
+    qualify - 3x3, plain sources all GroupNorm-activated or all stored, Cout a multiple of 128, Cin of 16, planes of whole
+    8 x 32 tiles - against the torch-CPU conv and the classic kernel.  norm: one tile per workgroup; norm_multi_tile: several
+    tiles per workgroup with an image change inside a range (statistics flushed per image); norm_concat_pad: skip || up-path
+    concat with the second source smaller and offset (unet_model.py:86-92; chunks switch source at 48 channels);
+    raw_bias_relu: stored source, bias + ReLU epilogue, no statistics (input-gradient / VGG form); raw_odd_items: an odd item
+    count per workgroup (the staging loop's padding half); half_chip: grid sized by cu_limit."""
+    n, cins, cout, h, w = {"norm": (8, (64,), 128, 64, 96), "norm_multi_tile": (13, (32,), 256, 40, 96),
+                           "norm_concat_pad": (8, (48, 32), 128, 64, 96), "raw_bias_relu": (8, (144,), 256, 64, 96),
+                           "raw_odd_items": (3, (176,), 128, 40, 32), "half_chip": (8, (64,), 128, 64, 96)}[case]
+    cin = sum(cins)
+    wt = rnd(cout, cin, 3, 3, seed=52, scale=0.1)
+    norm = case.startswith("norm") or case == "half_chip"
+    srcs = []
+    for i, c in enumerate(cins):
+        hs, ws, off = (h, w, (0, 0)) if i == 0 else (h - 3, w - 5, (1, 2))
+        x = rnd(n, c, hs, ws, seed=53 + i)
+        if norm:
+            sc, sh = gn_affine(n, c, 55 + i)
+            srcs.append(U.SrcSpec(x, L.SRC_NORM, L.SP_NONE, sc, sh, off=off))
+        else:
+            srcs.append(U.SrcSpec(x, off=off))
+    bias = rnd(cout, seed=57) if case == "raw_bias_relu" else None
+    ran = []
+    kw = dict(bias=bias, with_stats=case != "raw_bias_relu", variant=ran)
+    if case in ("half_chip", "raw_odd_items"):
+        kw["cu_limit"] = 128 if case == "half_chip" else 16
+    if case == "raw_bias_relu":
+        kw["relu_out"] = 1
+    out, stats = U.conv_forward(dt, srcs, wt, h, w, 3, **kw)
+    assert ran[0].startswith("conv_pc_kernel<"), ran
+    ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w), U.rounded(wt, dt), bias, padding=1)
+    if case == "raw_bias_relu":
+        ref = F.relu(ref)
+    assert torch.isfinite(out).all()
+    assert U.relerr(out, ref) <= (TOL_NORM[dt] if norm else TOL_OUT[dt])
+    if kw["with_stats"]:
+        o = ref.view(n, 8, cout // 8, h, w).double()      # (the kernel sums its fp32 accumulators, before the storage rounding)
+        assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-4 * o.abs().sum((2, 3, 4)).max().item())
+        assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-3)
+    ran2 = []
+    kw["variant"] = ran2
+    out2, stats2 = U.conv_forward(dt, srcs, wt, h, w, 3, use_ring=False, **kw)
+    assert ran2[0].startswith("conv_igemm_kernel<"), ran2
+    assert U.relerr(out, out2) <= TOL_OUT[dt]
+    if kw["with_stats"]:
+        assert torch.allclose(stats, stats2, rtol=1e-3, atol=1e-3 * float(stats2.abs().max()))
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv1x1_and_bias(dt):
     n, cin, cout, h, w = 2, 64, 32, 20, 36
@@ -668,7 +720,8 @@ def test_norm_pool2_and_upsample2(dt, shape):
 
 
 @pytest.mark.parametrize("dt", [L.BF16, L.F16])
-@pytest.mark.parametrize("shape", [(2, 64, 64, 11, 19), (1, 128, 256, 32, 32), (2, 96, 128, 8, 5), (1, 32, 64, 1, 3)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 11, 19), (1, 128, 256, 32, 32), (2, 96, 128, 8, 5), (1, 32, 64, 1, 3),
+                                   (1, 64, 1024, 6, 7)])      # last: a GroupNorm group spans two 64-channel blocks (C5's bottom)
 def test_up_conv1x1_fused(dt, shape):
     """csrc/up_fused.hip: bilinear x2 (align_corners) of conv1x1(LeakyReLU(GroupNorm(x))) + GroupNorm statistics in one launch,
     against nn.Upsample -> nn.Conv2d(1x1) evaluated in the reference's order (unet_model.py:71-72) - the two linear maps
@@ -691,7 +744,7 @@ def test_up_conv1x1_fused(dt, shape):
     # statistics of the tensor as stored (the kernel sums the fp32 interpolated values before rounding: storage tolerance)
     o = got.view(n, 8, cout // 8, 2 * h, 2 * w).double()
     st = stats.cpu().view(L.STAT_SLOTS, n, 8, 2).sum(0)
-    assert torch.allclose(st[..., 0], o.sum((2, 3, 4)), rtol=2e-3, atol=2e-2 * o.abs().max().item())
+    assert torch.allclose(st[..., 0], o.sum((2, 3, 4)), rtol=2e-3, atol=1e-3 * o.abs().sum((2, 3, 4)).max().item())
     assert torch.allclose(st[..., 1], (o * o).sum((2, 3, 4)), rtol=5e-3)
 
 
