@@ -15,8 +15,9 @@
 //   * waves 4-7 only stage: buffer loads of the item after next into registers (halo tile 10 x 34 pixels x 16 channels and
 //     the item's 36-KiB weight image), GroupNorm + LeakyReLU on the halo vectors that have arrived, LDS stores.
 // Work item = 8 x 32 pixels x 128 output channels x 16 input channels (32-byte LDS rows, the ring kernel's layouts: the
-// weight image is the ring-packed one, [cout block][cin chunk][tap][128 rows][32 B], slots pre-swizzled).  Two LDS
-// buffers + two register sets: an item's loads are issued two items (~3 us) before its commit.  One barrier per item.
+// weight image is the ring-packed one, [cout block][cin chunk][tap][128 rows][32 B], slots pre-swizzled).  Three LDS
+// buffers + two register sets: an item's loads are issued two items (~3 us) before its commit.  The roles hand items over
+// through two LDS counters, not workgroup barriers (see pc_signal / pc_wait_ge).
 #include <mutex>
 #include <type_traits>
 
@@ -43,6 +44,8 @@ __device__ unsigned long long g_pc_cycles[8][12];
 #define MRISR_PC_AD 3        // weight-fragment prefetch distance (fragments)
 #endif
 
+typedef __attribute__((ext_vector_type(2))) float pc_f32x2;      // pairs for v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+
 constexpr int kPcThreads = 512;
 constexpr int kPcBN = 128;                       // output channels per workgroup
 constexpr int kPcHaloW = 34, kPcHaloH = 10, kPcHaloRows = kPcHaloW * kPcHaloH;     // 8 x 32 pixel tile + halo
@@ -51,7 +54,38 @@ constexpr int kPcHaloBytes = 256 * kPcHaloSlots * 16;        // (the last slot s
 constexpr int kPcWBytes = 9 * kPcBN * 32;        // weight image of one (cout block, cin chunk)
 constexpr int kPcWSlots = kPcWBytes / (256 * 16);
 constexpr int kPcBuf = kPcHaloBytes + kPcWBytes;
-static_assert(kPcWSlots * 256 * 16 == kPcWBytes, "whole slots");
+constexpr int kPcStages = 3;                     // LDS item buffers (3 x 48 KiB)
+constexpr int kPcLds = kPcStages * kPcBuf + kPcBN * 4 + 64;      // + bias table + the two item counters
+
+// Item counters in LDS instead of workgroup barriers: the staging waves may run up to two items ahead of the MFMA waves
+// (they keep staging while a tile's epilogue runs) and nobody waits for the slowest wave of the OTHER role at every item.
+//   ready[w]: items stored by staging wave w, bumped behind its LDS stores of an item -> item c can be read when all four
+//             are >= c + 1;   done[w]: items read by MFMA wave w, bumped behind its last fragment read of an item -> the
+//             buffer of item c can be rewritten when all four are >= c + 1
+// (one counter per WAVE: the waves of a role are not synchronised with each other, a sum would let a fast wave's count stand
+// in for a slow one's).  LDS instructions of one wave execute in issue order, so the increment lands behind the stores / reads
+// it publishes; the asm statements are compiler barriers for memory operations.  A wave that waits unreasonably long stops
+// waiting for good (results are then wrong, but the kernel ends: a mis-count must never hang the GPU).
+__device__ __forceinline__ void pc_signal(unsigned lds_addr) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(lds_addr), "v"(1u) : "memory");
+}
+// (the polls are volatile LDS loads, not asm: hipcc's own `s_waitcnt lgkmcnt` bookkeeping must see every LDS operation)
+__device__ __forceinline__ int pc_min4(const u32x4 v) { return min(min((int)v[0], (int)v[1]), min((int)v[2], (int)v[3])); }
+__device__ __forceinline__ u32x4 pc_peek(const unsigned* cnt4) {
+    return *reinterpret_cast<const volatile u32x4*>(cnt4);
+}
+// `seen`: a peek taken earlier (the answer is usually already there: no LDS round trip on the critical path)
+__device__ __forceinline__ void pc_wait_ge(const unsigned* cnt4, u32x4 seen, int target, bool& broken) {
+    if (!broken && target > 0) {
+        int spin = 0;
+        while (__builtin_amdgcn_readfirstlane(pc_min4(seen)) < target) {
+            if (++spin > (1 << 21)) { broken = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+            seen = pc_peek(cnt4);
+        }
+    }
+    asm volatile("" ::: "memory");
+}
 
 template <typename T, bool NORM, bool STATS>
 __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams p_in) {
@@ -62,7 +96,13 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool consumer = wave < 4;
-    float* lds_bias = reinterpret_cast<float*>(smem + 2 * kPcBuf);
+    float* lds_bias = reinterpret_cast<float*>(smem + kPcStages * kPcBuf);
+    unsigned* lds_cnt = reinterpret_cast<unsigned*>(smem + kPcStages * kPcBuf + kPcBN * 4);
+    const unsigned ready_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kPcStages * kPcBuf + kPcBN * 4);
+    const unsigned done_a = ready_a + 32;
+    const unsigned* ready_p = lds_cnt;
+    const unsigned* done_p = lds_cnt + 8;
+    bool broken = false;
 
     // XCD-aware workgroup order (conv_fwd.hip): the cout blocks of a tile range, then the neighbouring ranges, share an L2
     int bid = blockIdx.x;
@@ -74,6 +114,8 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     const int bn0 = cb * BN;
     if (total <= 0) return;
     if (t < BN) lds_bias[t] = p.bias ? gload<float>(p.bias + bn0 + t) : 0.f;
+    if (t < 16) lds_cnt[t] = 0u;
+    __syncthreads();                    // the only workgroup barrier: bias table and counters are set up
 
     auto decode = [&](int tile, int& n, int& ty0, int& tx0) {
         const int tx = tile % p.tiles_x;
@@ -83,10 +125,11 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         tx0 = tx * 32;
     };
 
-    // ------------------------------------------------------------------ schedule: one barrier per item
-    //   consumers:  MFMA(item k) from buffer k & 1 (+ the tile's epilogue behind its last item)
-    //   producers:  commit(item k+1) into buffer (k+1) & 1  ->  issue loads(item k+3) into the registers just freed
-    // Two separate loops with the same barrier sequence: neither role's registers are live in the other's code.
+    // ------------------------------------------------------------------ schedule
+    //   consumers:  wait ready(k) -> MFMA(item k) from buffer k % 3 -> signal done (+ the tile's epilogue behind its last item)
+    //   producers:  wait done(k - 3) -> commit(item k) into buffer k % 3 -> signal ready -> issue loads(item k+2) into the
+    //               registers just freed
+    // Two separate loops: neither role's registers are live in the other's code.
     if (!consumer) {
         // ------------------------------------------------------------------ producer (waves 4-7): 256 staging threads
         const int pt = t & 255;
@@ -97,7 +140,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         struct StageSet {
             Vec16<T> h[kPcHaloSlots];
             u32x4 w[kPcWSlots];
-            float sc[VEC], sh[VEC];
+            pc_f32x2 sc[VEC / 2], sh[VEC / 2];     // GroupNorm affine of this thread's 8 channels, as pairs (packed fp32 math)
             int ty0, tx0, w1;
         };
         StageSet S0, S1;
@@ -110,14 +153,28 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
             const_cast<void*>(two ? p.src[1].ptr : p.src[0].ptr), 0, (int)((unsigned)p.N * (two ? p.src[1].img_bytes : p.src[0].img_bytes)), 0x00020000);
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(p.wpacked), 0, (int)((unsigned)p.ncb * p.nchunks * kPcWBytes), 0x00020000);
+        // GroupNorm scale / shift [N][C] floats of each source: buffer loads with a scalar offset (no per-load address arithmetic)
+        const __amdgpu_buffer_rsrc_t sc_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.src[0].scale), 0, NORM ? (int)((unsigned)p.N * p.src[0].C * 4u) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t sh_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.src[0].shift), 0, NORM ? (int)((unsigned)p.N * p.src[0].C * 4u) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t sc_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(two ? p.src[1].scale : p.src[0].scale), 0, NORM ? (int)((unsigned)p.N * (two ? p.src[1].C : p.src[0].C) * 4u) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t sh_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(two ? p.src[1].shift : p.src[0].shift), 0, NORM ? (int)((unsigned)p.N * (two ? p.src[1].C : p.src[0].C) * 4u) : 0, 0x00020000);
         unsigned rel0[kPcHaloSlots], rel1[kPcHaloSlots];
+        // edge flags of this thread's slots, 4 bits each: halo row 0 / row 9 / column 0 / column 33 (rows >= 340: none)
+        unsigned fflags = 0;
 #pragma unroll
         for (int j = 0; j < kPcHaloSlots; ++j) {
             const int row = hrow0 + 128 * j;
             const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;        // row / 34 for row < 1000
             rel0[j] = (unsigned)((hy * p.src[0].W + hx) * p.src[0].C + lslot * VEC) * 2u;
             rel1[j] = two ? (unsigned)((hy * p.src[1].W + hx) * p.src[1].C + lslot * VEC) * 2u : rel0[j];
+            if (row < kPcHaloRows)
+                fflags |= (unsigned)((hy == 0 ? 1 : 0) | (hy == kPcHaloH - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == kPcHaloW - 1 ? 8 : 0)) << (4 * j);
         }
+        const int aff_v = lslot * VEC * 4;         // byte offset of this thread's 8 channels inside a chunk's 16
         const unsigned wv = (unsigned)pt * 16u;
 
         // Loads of item (tile at n, ty0, tx0; chunk kc) into S.  STRAIGHT-LINE: no branch around a load (conv_wgrad_rows.hip:
@@ -140,16 +197,30 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
 #pragma unroll
             for (int j = 0; j < kPcWSlots; ++j)
                 S.w[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(wv + 4096u * j), woff, 0);
+#ifdef PC_GLOBAL_AFF
             if (NORM) {
                 const float* scp = (w1 ? p.src[1].scale : p.src[0].scale) + (size_t)n * Cs + cs + lslot * VEC;
                 const float* shp = (w1 ? p.src[1].shift : p.src[0].shift) + (size_t)n * Cs + cs + lslot * VEC;
 #pragma unroll
                 for (int e = 0; e < VEC; e += 4) {
                     const f32x4 a = gload<f32x4>(scp + e), b = gload<f32x4>(shp + e);
-                    S.sc[e] = a[0]; S.sc[e + 1] = a[1]; S.sc[e + 2] = a[2]; S.sc[e + 3] = a[3];
-                    S.sh[e] = b[0]; S.sh[e + 1] = b[1]; S.sh[e + 2] = b[2]; S.sh[e + 3] = b[3];
+                    S.sc[e / 2] = pc_f32x2{a[0], a[1]}; S.sc[e / 2 + 1] = pc_f32x2{a[2], a[3]};
+                    S.sh[e / 2] = pc_f32x2{b[0], b[1]}; S.sh[e / 2 + 1] = pc_f32x2{b[2], b[3]};
                 }
             }
+#else
+            if (NORM) {
+                const int aoff = (n * Cs + cs) * 4;
+                const __amdgpu_buffer_rsrc_t scr = w1 ? sc_rsrc1 : sc_rsrc0, shr = w1 ? sh_rsrc1 : sh_rsrc0;
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(scr, aff_v + e * 4, aoff, 0));
+                    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shr, aff_v + e * 4, aoff, 0));
+                    S.sc[e / 2] = pc_f32x2{a[0], a[1]}; S.sc[e / 2 + 1] = pc_f32x2{a[2], a[3]};
+                    S.sh[e / 2] = pc_f32x2{b[0], b[1]}; S.sh[e / 2 + 1] = pc_f32x2{b[2], b[3]};
+                }
+            }
+#endif
             S.ty0 = ty0; S.tx0 = tx0; S.w1 = w1 ? 1 : 0;
         };
         PPT_DECL
@@ -165,9 +236,20 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                 Vec16<T> v = S.h[j];
                 if (NORM && !(MRISR_PC_DBG & 2)) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const float y = fmaf(v.get(e), S.sc[e], S.sh[e]);
-                        v.set(e, fmaxf(y, LRELU_SLOPE * y));
+                    for (int e = 0; e < VEC; e += 2) {
+                        // scalar fp32 math on purpose: v_pk_fma_f32 / v_pk_mul_f32 beside the other wave's MFMAs made this
+                        // loop ~3x slower (down1.3 forward 82 -> 105 us, A/B)
+                        const float ya = fmaf(v.get(e), S.sc[e / 2][0], S.sh[e / 2][0]), yb = fmaf(v.get(e + 1), S.sc[e / 2][1], S.sh[e / 2][1]);
+#ifdef PC_PK
+                        const pc_f32x2 x = {v.get(e), v.get(e + 1)};
+                        const pc_f32x2 y = __builtin_elementwise_fma(x, S.sc[e / 2], S.sh[e / 2]);
+                        const pc_f32x2 y2 = y * LRELU_SLOPE;
+                        v.set(e, fmaxf(y[0], y2[0]));
+                        v.set(e + 1, fmaxf(y[1], y2[1]));
+                        continue;
+#endif
+                        v.set(e, fmaxf(ya, LRELU_SLOPE * ya));
+                        v.set(e + 1, fmaxf(yb, LRELU_SLOPE * yb));
                     }
                 }
                 *reinterpret_cast<decltype(v.v)*>(lds_h + (q + 256 * j) * 16) = v.v;
@@ -186,13 +268,24 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
             if (!interior) {
                 Vec16<T> z;
                 z.zero();
+                // at most the outermost halo ring lies outside (every layer of the network: the source covers the plane): the
+                // tile's four edge bits against the slots' precomputed ones
+                const bool ring_only = ys0 >= -1 && xs0 >= -1 && ys0 + kPcHaloH <= Hs + 1 && xs0 + kPcHaloW <= Ws + 1;
+                if (ring_only) {
+                    const unsigned tm = (ys0 < 0 ? 1u : 0u) | (ys0 + kPcHaloH > Hs ? 2u : 0u) | (xs0 < 0 ? 4u : 0u) | (xs0 + kPcHaloW > Ws ? 8u : 0u);
+                    const unsigned hit = fflags & (tm * 0x111u);
 #pragma unroll
-                for (int j = 0; j < kPcHaloSlots; ++j) {
-                    const int row = (q >> 1) + 128 * j;
-                    const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;
-                    const unsigned y = ys0 + hy, x = xs0 + hx;
-                    if (row < kPcHaloRows && !(y < (unsigned)Hs && x < (unsigned)Ws))
-                        *reinterpret_cast<decltype(z.v)*>(lds_h + (q + 256 * j) * 16) = z.v;
+                    for (int j = 0; j < kPcHaloSlots; ++j)
+                        if (hit & (0xfu << (4 * j))) *reinterpret_cast<decltype(z.v)*>(lds_h + (q + 256 * j) * 16) = z.v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kPcHaloSlots; ++j) {
+                        const int row = (q >> 1) + 128 * j;
+                        const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;
+                        const unsigned y = ys0 + hy, x = xs0 + hx;
+                        if (row < kPcHaloRows && !(y < (unsigned)Hs && x < (unsigned)Ws))
+                            *reinterpret_cast<decltype(z.v)*>(lds_h + (q + 256 * j) * 16) = z.v;
+                    }
                 }
             }
         };
@@ -215,25 +308,30 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         step();
         issue(S1, ln, lty0, ltx0, l_kc);
         step();
-        commit_issue(S0, smem, ln, lty0, ltx0, l_kc);
-        step();
-        __syncthreads();
         PPT_MARK(8)
         // two items per trip, no exit between them (with a `break` in the middle hipcc's wait-count pass merges the two halves
-        // conservatively: `vmcnt(0)` before the first half's commit, i.e. a wait for the loads issued one barrier ago); an odd
-        // item count is padded with a staging-only half - the consumers run the same number of barriers
+        // conservatively: `vmcnt(0)` before the first half's commit, i.e. a wait for the loads issued one item ago); an odd
+        // item count is padded with a half that stages the last item again into a buffer nobody reads
+        int bi = 0;                 // buffer of the item to commit = item % 3
+        u32x4 dseen = {0u, 0u, 0u, 0u};
 #pragma unroll 1
         for (int c = 0; c < total; c += 2) {
-            commit_issue(S1, smem + kPcBuf, ln, lty0, ltx0, l_kc);
-            step();
-            PPT_MARK(6)
-            __syncthreads();
+            pc_wait_ge(done_p, dseen, c - 2, broken);         // item c - 3 (same buffer) has been read by all four MFMA waves
             PPT_MARK(5)
-            commit_issue(S0, smem, ln, lty0, ltx0, l_kc);
+            commit_issue(S0, smem + bi * kPcBuf, ln, lty0, ltx0, l_kc);
+            if (lane == 0) pc_signal(ready_a + 4 * (wave - 4));
+            dseen = pc_peek(done_p);
             step();
+            bi = bi == kPcStages - 1 ? 0 : bi + 1;
             PPT_MARK(6)
-            __syncthreads();
+            pc_wait_ge(done_p, dseen, c - 1, broken);
             PPT_MARK(5)
+            commit_issue(S1, smem + bi * kPcBuf, ln, lty0, ltx0, l_kc);
+            if (lane == 0) pc_signal(ready_a + 4 * (wave - 4));
+            dseen = pc_peek(done_p);
+            step();
+            bi = bi == kPcStages - 1 ? 0 : bi + 1;
+            PPT_MARK(6)
         }
         PPT_DUMP()
         return;
@@ -263,11 +361,11 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     // GroupNorm partial sums per lane: a group spans >= 16 channels here (host-checked), i.e. the quad pairs {0,1} and {2,3}
     // of a fragment each lie in one group
     constexpr int NSQ = STATS ? 2 : 1;
-    float st_s[NI][NSQ], st_ss[NI][NSQ];
+    pc_f32x2 st_s[NI][NSQ], st_ss[NI][NSQ];       // pairs: v_pk_add_f32 / v_pk_fma_f32 straight from the accumulator registers
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int q = 0; q < NSQ; ++q) { st_s[ni][q] = 0.f; st_ss[ni][q] = 0.f; }
+        for (int q = 0; q < NSQ; ++q) { st_s[ni][q] = pc_f32x2{0.f, 0.f}; st_ss[ni][q] = pc_f32x2{0.f, 0.f}; }
 
     // epilogue of a finished tile (as conv_ring.hip): bias / ReLU, GroupNorm partial sums, packed 16-bit values exchanged
     // between the lane halves (permlane32) -> 16-byte stores.  Whole tiles only (host-checked): no predication.
@@ -302,10 +400,16 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                         acc[ni][mi][4 * q + j] = 0.f;
                     }
                     if (STATS) {
-                        const float qs = (v[0] + v[1]) + (v[2] + v[3]);
-                        const float qq = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                        st_s[ni][q >> 1] += qs;
-                        st_ss[ni][q >> 1] += qq;
+#ifdef PC_STATS_NOPK
+                        st_s[ni][q >> 1][0] += (v[0] + v[1]) + (v[2] + v[3]);
+                        st_ss[ni][q >> 1][0] += fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                        continue;
+#endif
+                        const pc_f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+                        st_s[ni][q >> 1] += v01;
+                        st_s[ni][q >> 1] += v23;
+                        st_ss[ni][q >> 1] = __builtin_elementwise_fma(v01, v01, st_ss[ni][q >> 1]);
+                        st_ss[ni][q >> 1] = __builtin_elementwise_fma(v23, v23, st_ss[ni][q >> 1]);
                     }
                     typedef __attribute__((ext_vector_type(4))) T t4_t;
                     union { t4_t b; u32x2 u; } cv;
@@ -331,30 +435,29 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
             for (int q = 0; q < NSQ; ++q) {
                 int co = bn0 + ni * 32 + 16 * q + 4 * lh;
                 asm volatile("" : "+v"(co));
-                const float s = half_wave_sum(st_s[ni][q]), ss = half_wave_sum(st_ss[ni][q]);
+                const float s = half_wave_sum(st_s[ni][q][0] + st_s[ni][q][1]), ss = half_wave_sum(st_ss[ni][q][0] + st_ss[ni][q][1]);
                 if (lr == 0) {
                     const int g = co / gs;
                     double* sp = p.stats + stat_slot_off_id(bid, p.N, p.groups) + ((size_t)n * p.groups + g) * 2;
                     atomic_add_f64(sp, (double)s);
                     atomic_add_f64(sp + 1, (double)ss);
                 }
-                st_s[ni][q] = 0.f;
-                st_ss[ni][q] = 0.f;
+                st_s[ni][q] = pc_f32x2{0.f, 0.f};
+                st_ss[ni][q] = pc_f32x2{0.f, 0.f};
             }
     };
 
     int tile = bt0, kc = 0, n, ty0, tx0;
     decode(tile, n, ty0, tx0);
-    __syncthreads();
     PPT_DECL
-    const int total2 = (total + 1) & ~1;       // (the staging loop runs two items per trip)
+    int bi = 0;
+    u32x4 rseen = {0u, 0u, 0u, 0u};
 #pragma unroll 1
-    for (int c = 0; c < total2; ++c) {
-        if (c >= total) {
-            __syncthreads();
-            break;
-        }
-        const char* buf = smem + (c & 1) * kPcBuf;
+    for (int c = 0; c < total; ++c) {
+        pc_wait_ge(ready_p, rseen, c + 1, broken);      // all four staging waves have stored item c
+        PPT_MARK(5)
+        const char* buf = smem + bi * kPcBuf;
+        bi = bi == kPcStages - 1 ? 0 : bi + 1;
         const char* wl = buf + a_off;
         // Fragment pipeline (conv_ring.hip): pixel fragments of tap t+1 and weight fragments up to AD steps ahead are requested
         // before the MFMAs that use the current ones are issued
@@ -378,6 +481,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                 const int idx = tap * NI + ni;
                 if (idx + AD < 9 * NI) load_a(idx + AD);
                 if (ni == 0 && tap + 1 < 9) load_b(tap + 1, (tap + 1) & 1);
+                if (tap == 7 && ni == 0) rseen = pc_peek(ready_p);      // is the next item there?  (answer used at its start)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -387,6 +491,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (lane == 0) pc_signal(done_a + 4 * wave);       // (behind this wave's last fragment read of the item, in LDS issue order)
         PPT_MARK(6)
         if (++kc == p.nchunks) {
             if (!(MRISR_PC_DBG & 4)) epilogue(n, ty0, tx0);
@@ -397,8 +502,6 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
             if (STATS && (tile >= bt1 || n != n_prev)) flush_stats(n_prev);
             PPT_MARK(4)
         }
-        __syncthreads();
-        PPT_MARK(5)
     }
     PPT_DUMP()
 }
@@ -456,7 +559,7 @@ static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream
     p.tiles_per_block = ceil_div(p.ntiles, per_cb);
     per_cb = ceil_div(p.ntiles, p.tiles_per_block);
     const int grid = per_cb * p.ncb;
-    const size_t lds = 2 * kPcBuf + kPcBN * sizeof(float);
+    const size_t lds = kPcLds;
     const bool norm = d->src[0].mode == MRISR_SRC_NORM, stats = d->stats != nullptr;
     static std::once_flag once;
     std::call_once(once, [] {
