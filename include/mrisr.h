@@ -243,6 +243,19 @@ typedef struct mrisr_gn_bwd_fin {
 int mrisr_act_bwd_apply_fused(int dtype, const void* x, const float* scale, const float* shift, int nconsumers,
                               const mrisr_consumer* consumers, const float* blend_alpha, const float* coef,
                               const mrisr_gn_bwd_fin* fin, void* dx, int N, int H, int W, int C, void* stream);
+/* ONE-PASS form of mrisr_act_bwd_reduce + mrisr_act_bwd_apply_fused (csrc/norm.hip: act_bwd_onepass_kernel) for nodes whose
+ * consumers are all plain (MRISR_SP_NONE), have the node's geometry and no blend weight; 16-bit storage.  x and every
+ * consumer gradient are read from HBM once instead of twice: the blocks of an image keep their operands in registers across
+ * an in-kernel image barrier (`arrive`: [N][mrisr_act_bwd_onepass_barrier_words()] uint32).  red ([mrisr_act_bwd_onepass_slots()][N][C][2] fp32, = fin->red:
+ * the per-(n,c) sums spread over 16 copies) and arrive must be ZERO on entry.  mrisr_act_bwd_onepass_ok() != 0 tells whether a node qualifies (channel count, blocks per image <= 256: one
+ * image's blocks must be resident together); the entry point refuses the others with MRISR_E_UNSUPPORTED.
+ * Replaces the GroupNorm + LeakyReLU part of autograd's backward of DoubleConv (/root/reference/models/unet_model.py:28-37). */
+int mrisr_act_bwd_onepass_slots(void);
+int mrisr_act_bwd_onepass_barrier_words(void);
+int mrisr_act_bwd_onepass_ok(int dtype, int nconsumers, const mrisr_consumer* consumers, int N, int H, int W, int C);
+int mrisr_act_bwd_onepass(int dtype, const void* x, const float* scale, const float* shift, const float* meanrstd,
+                          int nconsumers, const mrisr_consumer* consumers, float* red, uint32_t* arrive,
+                          const mrisr_gn_bwd_fin* fin, void* dx, int N, int H, int W, int C, void* stream);
 /* the same for a pixel-shuffled node (unet_model.py:102): one plain consumer with the node's geometry, even H and W; dx
  * is stored un-shuffled as [N][H/2][W/2][4C] (channel 4c + 2(Y&1) + (X&1)) and dbias (optional, [4C] fp32 accumulated) +=
  * the channel sums of dx = the producing conv's bias gradient (as mrisr_act_bwd_apply's PIXEL_SHUFFLE2 mode).       */

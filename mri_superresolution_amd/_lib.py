@@ -91,6 +91,11 @@ SIGNATURES = {
     "mrisr_act_bwd_apply": (_i, [_i, _vp, _vp, _fp, _vp, _i, _i, _i, _i, _i, _fp, _vp]),
     "mrisr_act_bwd_apply_fused": (_i, [_i, _vp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _fp, C.POINTER(GnBwdFin), _vp, _i, _i,
                                        _i, _i, _vp]),
+    "mrisr_act_bwd_onepass_slots": (_i, []),
+    "mrisr_act_bwd_onepass_barrier_words": (_i, []),
+    "mrisr_act_bwd_onepass_ok": (_i, [_i, _i, C.POINTER(Consumer), _i, _i, _i, _i]),
+    "mrisr_act_bwd_onepass": (_i, [_i, _vp, _fp, _fp, _fp, _i, C.POINTER(Consumer), _fp, _vp, C.POINTER(GnBwdFin), _vp, _i, _i, _i,
+                                   _i, _vp]),
     "mrisr_act_bwd_apply_fused_unshuffle": (_i, [_i, _vp, _fp, _fp, C.POINTER(Consumer), _fp, C.POINTER(GnBwdFin), _vp, _fp, _i,
                                                  _i, _i, _i, _vp]),
     "mrisr_channel_sum": (_i, [_i, _vp, _fp, _sz, _i, _vp]),
@@ -117,7 +122,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 301      # mrisr_version() of the library these struct layouts and signatures belong to
+ABI_VERSION = 302      # mrisr_version() of the library these struct layouts and signatures belong to
 
 
 def load():

@@ -828,6 +828,233 @@ __global__ __launch_bounds__(256) void act_bwd_apply_fused_kernel(const ActBwdPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE-PASS GroupNorm + LeakyReLU backward (plain consumers with the node's own geometry, 16-bit storage): what
+// act_bwd_reduce_kernel<T,0> + act_bwd_apply_fused_kernel<T,true> do in two launches that each read x and every consumer
+// gradient from HBM (5 tensor passes for one consumer, 7 for two), in one launch that reads them ONCE (3 / 4 passes):
+// a block keeps its pixels' x and consumer-gradient vectors in registers across the reduction.
+//   phase 1: per-(n,c) sums of g and g*xhat of the block's pixels -> atomics into red[n][c][2] (as the reduce kernel)
+//   image barrier: the blocks of image n count themselves in arrive[n] and wait until all of them have
+//   phase 2: coefficients from red[n] (as gn_bwd_coefs), dx from the registers
+// The barrier is safe because the workgroups of a 2-D grid start in linear order (x fastest): the blocks of image n are
+// all dispatched before any block of image n+1, so the ones a waiting block needs are resident or next in line - as long
+// as ONE image's blocks fit on the chip together, which the host guarantees with a wide margin (<= 256 blocks of 256
+// threads per image against >= 480 resident ones with the weight-gradient stream holding its share of the CUs).  A block
+// that waits unreasonably long (~0.3 s) gives up and poisons its output with NaN: a broken assumption must neither hang the
+// GPU nor pass silently.
+constexpr int kOnePassPPT = 8;       // pixels per thread
+constexpr int kOnePassMaxBlocks = 256;
+// the per-(n,c) sums are spread over this many copies of red[] (block index mod kOnePassSlots): the blocks of an image all
+// add into the same C x 2 words right before they wait for each other, and 256 same-address atomics in a row (performed at
+// the memory side) took ~25 us per image
+constexpr int kOnePassSlots = 16;
+constexpr int kOnePassGroups = 16;      // block groups of the image barrier
+constexpr int kOnePassWords = 544;      // barrier words per image: 16 group counters, the image counter, 16 group flags - 64 bytes apart
+
+__device__ __forceinline__ float ld_coherent(const float* p) {      // red[] is written by other blocks of THIS launch
+    return __hip_atomic_load((const GLOBAL_AS float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int NCONS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void act_bwd_onepass_kernel(const ActBwdParams p, T* __restrict__ dx, const FinDev fin,
+                                                              unsigned* __restrict__ arrive) {
+    constexpr int VEC = Vec16<T>::N, PPT = kOnePassPPT;
+    __shared__ float lds[256 * VEC * 2 + 2 * kMaxGroups];
+    __shared__ int timed_out;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = p.C / VEC, ppb = 256 / nvec;             // host-checked: nvec is a power of two <= 256
+    const int cv = t & (nvec - 1), pl = t / nvec, c = cv * VEC;
+    const int HW = p.H * p.W, gs = p.C / p.groups;
+    const int pix0 = blockIdx.x * (ppb * PPT) + pl;
+
+    float sc[VEC], sh[VEC];
+    const size_t k0 = (size_t)n * p.C + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sc[e] = p.scale[k0 + e]; sh[e] = p.shift[k0 + e]; }
+    const T* xb = (const T*)p.x + (size_t)n * HW * p.C + c;
+    const T* d0b = (const T*)p.cons[0].da + (size_t)n * HW * p.cons[0].C_total + p.cons[0].c_off + c;
+    const T* d1b = NCONS > 1 ? (const T*)p.cons[1].da + (size_t)n * HW * p.cons[1].C_total + p.cons[1].c_off + c : d0b;
+    const int ct0 = p.cons[0].C_total, ct1 = NCONS > 1 ? p.cons[1].C_total : ct0;
+
+    // ---- phase 1: everything this thread will need, loaded once
+    Vec16<T> xv[PPT], d0[PPT], d1[NCONS > 1 ? PPT : 1];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pix = min(pix0 + i * ppb, HW - 1);          // (the tail block re-reads the last pixel; masked below)
+        xv[i] = load_vec16(xb + (size_t)pix * p.C);
+        d0[i] = load_vec16(d0b + (size_t)pix * ct0);
+        if (NCONS > 1) d1[i] = load_vec16(d1b + (size_t)pix * ct1);
+    }
+    float sA[VEC], sB[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sA[e] = 0.f; sB[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        if (pix0 + i * ppb < HW) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xr = xv[i].get(e);
+                const float pre = xr * sc[e] + sh[e];
+                const float ga = NCONS > 1 ? d0[i].get(e) + d1[i].get(e) : d0[i].get(e);
+                const float gy = ga * (pre > 0.f ? 1.f : LRELU_SLOPE);
+                sA[e] += gy;
+                sB[e] += gy * xr;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {      // sum g*xhat = rstd * (sum g*x - mean * sum g), per thread (8 pixels)
+        const int g = (c + e) / gs;
+        const float mean = p.meanrstd[((size_t)n * p.groups + g) * 2], rstd = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
+        sB[e] = rstd * (sB[e] - mean * sA[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        lds[(t * VEC + e) * 2] = sA[e];
+        lds[(t * VEC + e) * 2 + 1] = sB[e];
+    }
+    if (t == 0) timed_out = 0;
+    __syncthreads();
+    for (int i = t; i < nvec * VEC * 2; i += 256) {
+        const int j = i >> 1, which = i & 1;
+        const int cvj = j / VEC, e = j - cvj * VEC;
+        float s = 0.f;
+        for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
+        atomic_add_f32(&p.red[(((size_t)(blockIdx.x % kOnePassSlots) * p.N + n) * p.C + cvj * VEC + e) * 2 + which], s);
+    }
+    // ---- image barrier.  Everything that crosses it goes through agent-scope RELAXED atomics (the sums above, the counter,
+    // the reads of red[] below), which are performed at the memory side: no release / acquire fences - on this multi-XCD part
+    // each of them writes back or invalidates a whole L2, and with 4096 blocks doing so the launch ran 8x slower than the
+    // two launches it replaces.  `s_waitcnt vmcnt(0)`: this thread's atomics have been acknowledged before it is counted.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        // Two-level count, then a release flag per group of blocks: 256 blocks bumping and then polling ONE word is a chain of
+        // 256 same-address atomics at the memory side (~40 us per image, measured).  Block b belongs to group b % 16: it bumps
+        // its group's counter; the block that completes a group bumps the image's counter; the block that completes the image
+        // sets the 16 group flags; everybody polls its own group's flag (16 pollers per word, one cache line per word).
+        unsigned* img = arrive + (size_t)n * kOnePassWords;
+        const unsigned nblk = gridDim.x, g = blockIdx.x % kOnePassGroups;
+        const unsigned ngroups = min(nblk, (unsigned)kOnePassGroups), members = (nblk - g + kOnePassGroups - 1) / kOnePassGroups;
+        if (__hip_atomic_fetch_add(img + g * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == members) {
+            if (__hip_atomic_fetch_add(img + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == ngroups) {
+                for (unsigned k = 0; k < ngroups; ++k)
+                    __hip_atomic_store(img + 272 + k * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int spin = 0;
+        while (__hip_atomic_load(img + 272 + g * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(16);      // ~0.5 us between polls
+            if (++spin > 600000) { timed_out = 1; break; }
+        }
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    const bool bad = timed_out != 0;
+
+    // ---- phase 2: coefficients of image n (act_bwd_finalize_kernel's formulas; red read around the L1)
+    float* s12 = lds;
+    if (t < 2 * kMaxGroups) s12[t] = 0.f;
+    __syncthreads();
+    const float* rn = fin.red + (size_t)n * p.C * 2;
+    const size_t slot_stride = (size_t)p.N * p.C * 2;
+    float* sums = lds + 2 * kMaxGroups;            // [C][2]: the image's per-channel sums, all slots added up
+    for (int j = t; j < 2 * p.C; j += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < kOnePassSlots; ++sl) v += ld_coherent(rn + sl * slot_stride + j);
+        sums[j] = v;
+        atomicAdd(&s12[(j & 1) * kMaxGroups + (j >> 1) / gs], fin.gamma[j >> 1] * v);
+    }
+    __syncthreads();
+    float ca[VEC], cb[VEC], cc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (c + e) / gs;
+        const float mean = fin.meanrstd[((size_t)n * fin.groups + g) * 2], rstd = fin.meanrstd[((size_t)n * fin.groups + g) * 2 + 1];
+        const float S1 = s12[g] * fin.inv_count, S2 = s12[kMaxGroups + g] * fin.inv_count;
+        ca[e] = rstd * fin.gamma[c + e];
+        cb[e] = -rstd * rstd * S2;
+        cc[e] = bad ? __builtin_nanf("") : mean * rstd * rstd * S2 - rstd * S1;
+        if (blockIdx.x == 0 && pl == 0) {          // one block per image adds the image's share of dgamma / dbeta
+            atomic_add_f32(&fin.dbeta[c + e], sums[2 * (c + e)]);
+            atomic_add_f32(&fin.dgamma[c + e], sums[2 * (c + e) + 1]);
+        }
+    }
+    T* ob = dx + (size_t)n * HW * p.C + c;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pix = pix0 + i * ppb;
+        if (pix < HW) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xr = xv[i].get(e);
+                const float pre = xr * sc[e] + sh[e];
+                const float ga = NCONS > 1 ? d0[i].get(e) + d1[i].get(e) : d0[i].get(e);
+                const float gy = ga * (pre > 0.f ? 1.f : LRELU_SLOPE);
+                o.set(e, gy * ca[e] + xr * cb[e] + cc[e]);
+            }
+            store_vec16(ob + (size_t)pix * p.C, o);
+        }
+    }
+}
+
+// Does a node qualify for the one-pass kernel?  (16-bit storage, plain consumers of the node's own geometry without blend
+// weights, C / 8 a power of two <= 256, at most kOnePassMaxBlocks blocks per image)
+extern "C" int mrisr_act_bwd_onepass_ok(int dtype, int nconsumers, const mrisr_consumer* consumers, int N, int H, int W, int C) {
+    if (dtype != MRISR_BF16 && dtype != MRISR_F16) return 0;
+    if (!consumers || nconsumers < 1 || nconsumers > 2 || N < 1) return 0;
+    const int vec = mrisr_vec(dtype);
+    if (C % vec) return 0;
+    const int nvec = C / vec;
+    if (nvec > 256 || (nvec & (nvec - 1))) return 0;
+    for (int k = 0; k < nconsumers; ++k) {
+        const mrisr_consumer& c = consumers[k];
+        if (c.spatial != MRISR_SP_NONE || c.H != H || c.W != W || c.off_y || c.off_x || c.weight_mode) return 0;
+    }
+    const long HW = (long)H * W;
+    if (HW * C >= (1l << 30)) return 0;
+    const int ppblk = (256 / nvec) * kOnePassPPT;
+    return (HW + ppblk - 1) / ppblk <= kOnePassMaxBlocks ? 1 : 0;
+}
+
+// red: [kOnePassSlots = 16][N][C][2] floats and arrive: [N][kOnePassWords = 544] barrier words, both ZERO on entry (the engine's per-backward arena).
+extern "C" int mrisr_act_bwd_onepass_slots(void) { return kOnePassSlots; }
+extern "C" int mrisr_act_bwd_onepass_barrier_words(void) { return kOnePassWords; }
+extern "C" int mrisr_act_bwd_onepass(int dtype, const void* x, const float* scale, const float* shift, const float* meanrstd,
+                                     int nconsumers, const mrisr_consumer* consumers, float* red, unsigned* arrive,
+                                     const mrisr_gn_bwd_fin* fin, void* dx, int N, int H, int W, int C, void* stream) {
+    if (!x || !scale || !shift || !meanrstd || !consumers || !red || !arrive || !fin || !dx) MRISR_FAIL(MRISR_E_ARG, "act_bwd_onepass: null pointer");
+    if (!mrisr_act_bwd_onepass_ok(dtype, nconsumers, consumers, N, H, W, C))
+        MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_onepass: node does not qualify (mrisr_act_bwd_onepass_ok)");
+    if (fin->red != red || !fin->gamma || !fin->meanrstd || !fin->dgamma || !fin->dbeta) MRISR_FAIL(MRISR_E_ARG, "act_bwd_onepass: fin");
+    if (fin->groups <= 0 || fin->groups > kMaxGroups || C % fin->groups || !(fin->count > 0)) MRISR_FAIL(MRISR_E_SHAPE, "act_bwd_onepass: fin groups %d", fin->groups);
+    if (fin->alpha_slots) MRISR_FAIL(MRISR_E_UNSUPPORTED, "act_bwd_onepass: blend branches take the two-pass kernels");
+    FinDev fd;
+    memset(&fd, 0, sizeof(fd));
+    fd = FinDev{fin->red, fin->gamma, fin->meanrstd, fin->dgamma, fin->dbeta, nullptr, nullptr, nullptr,
+                (float)(1.0 / fin->count), fin->alpha_sign, fin->groups, nullptr, nullptr, nullptr};
+    ActBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.scale = scale; p.shift = shift; p.meanrstd = meanrstd; p.red = red;
+    p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C; p.groups = fin->groups;
+    int rc = fill_act_bwd_params(p, dtype, nconsumers, consumers, nullptr, H, W, C, "act_bwd_onepass");
+    if (rc) return rc;
+    const int nvec = C / mrisr_vec(dtype), ppblk = (256 / nvec) * kOnePassPPT;
+    dim3 grid(ceil_div(H * W, ppblk), N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MRISR_BF16) {
+        if (nconsumers == 1) act_bwd_onepass_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, fd, arrive);
+        else act_bwd_onepass_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, fd, arrive);
+    } else {
+        if (nconsumers == 1) act_bwd_onepass_kernel<f16_t, 1><<<grid, 256, 0, s>>>(p, (f16_t*)dx, fd, arrive);
+        else act_bwd_onepass_kernel<f16_t, 2><<<grid, 256, 0, s>>>(p, (f16_t*)dx, fd, arrive);
+    }
+    MRISR_CHECK_LAUNCH("act_bwd_onepass");
+    return MRISR_OK;
+}
+
 // out_mode PIXEL_SHUFFLE2: dx is stored un-shuffled, [N][H/2][W/2][4C] with channel 4c + 2(Y&1) + (X&1).  Thread =
 // one 16-byte vector of the DESTINATION (VEC/4 source channels x the 2x2 source pixels), so the stores are full
 // vectors; the (n, Y, X, c) -> destination scatter of 2-byte elements ran at a third of the plain kernel's rate.

@@ -444,7 +444,11 @@ class UNetEngine:
         # one zero-filled arena for the per-node (sum g, sum g*xhat) buffers instead of 20 small fills
         # (+256 floats per node: slots of the blend-alpha partial sums, used by the two head branches only)
         # (the head's input node: + N*(C+1) per-image partial sums of the head's own dW / db)
-        red_sizes = [N * n.C * 2 + 256 + (N * (n.C + 1) if n is self.head_in else 0) for n in self.nodes.values()]
+        # (+ the image-barrier words of the one-pass kernel)
+        # (the one-pass kernel spreads its sums over SL copies of [N][C][2]; the two-pass kernels use the first copy)
+        narr = N * L.load().mrisr_act_bwd_onepass_barrier_words()
+        SL = L.load().mrisr_act_bwd_onepass_slots() if es == 2 and not TUNING.no_onepass else 1
+        red_sizes = [SL * N * n.C * 2 + 256 + narr + (N * (n.C + 1) if n is self.head_in else 0) for n in self.nodes.values()]
         red_arena = torch.zeros(sum(red_sizes), dtype=torch.float32, device=dev)
         red_off = {}
         o = 0
@@ -483,15 +487,29 @@ class UNetEngine:
             # blend branches: dL/dalpha = sigmoid'(alpha) * sum dain * (act_bilinear - act_pixelshuffle) falls out of
             # the two branches' reduce passes (sum dain*act each), no extra pass over the three tensors
             wm0 = n.consumers[0][8]
-            slots = red[N * n.C * 2:] if (wm0 != 0 and n.consumers[0][5] == L.SP_NONE) else None
+            slots = red[SL * N * n.C * 2:] if (wm0 != 0 and n.consumers[0][5] == L.SP_NONE) else None
             # algorithmic traffic of the two passes: x once per pass, every consumer gradient once per pass (the channel window
             # the node owns; a pooled consumer's is a quarter of the node's size, the head's two one-channel fp32 maps), dx once
             nx = N * n.H * n.W * n.C * es
             nda = sum(N * c[3] * c[4] * (8 if c[5] == L.SP_HEAD else n.C * es) for c in n.consumers)
+            count = float((n.C // GN_GROUPS) * n.H * n.W)
+            if (fused and plain and slots is None and not uses_alpha and not TUNING.no_onepass
+                    and L.load().mrisr_act_bwd_onepass_ok(dt, len(n.consumers), cons, N, n.H, n.W, n.C)):
+                # plain consumers of the node's own geometry: ONE launch that reads x and the consumer gradients once and
+                # keeps them in registers across an in-kernel image barrier (csrc/norm.hip: act_bwd_onepass_kernel)
+                arrive = red[SL * N * n.C * 2 + 256:SL * N * n.C * 2 + 256 + narr]
+                fin = L.GnBwdFin(red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
+                                 grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), None, None, None,
+                                 count, 1.0, GN_GROUPS)
+                dx = torch.empty_like(n.raw)
+                L.call("mrisr_act_bwd_onepass", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                       n.meanrstd.data_ptr(), len(n.consumers), cons, red.data_ptr(), arrive.data_ptr(), C.byref(fin),
+                       dx.data_ptr(), N, n.H, n.W, n.C, st, nbytes=2 * nx + nda)
+                n.consumers = []
+                return dx
             L.call("mrisr_act_bwd_reduce", dt, n.raw.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
                    n.meanrstd.data_ptr(), len(n.consumers), cons, alpha_ptr, L.ptr(g), red.data_ptr(), L.ptr(slots),
                    N, n.H, n.W, n.C, GN_GROUPS, st, nbytes=nx + nda + (nx if g is not None else 0))
-            count = float((n.C // GN_GROUPS) * n.H * n.W)
             dalpha_ptr = grads["alpha"].data_ptr() if slots is not None else None
             if fused or fused_ps:
                 # the finalize step (group sums -> pass-2 coefficients, dgamma / dbeta / dalpha) runs inside the apply launch
@@ -530,7 +548,7 @@ class UNetEngine:
         # dL/dact = dz * w is never materialised: the node's two GroupNorm-backward passes form it on the fly from the
         # one-channel dz = dout * out * (1 - out), and the first pass accumulates the head's dW / db
         hn = self.head_in
-        ho = red_off[hn.name][0] + N * hn.C * 2 + 256
+        ho = red_off[hn.name][0] + SL * N * hn.C * 2 + 256 + narr
         hn.consumers.append((dout, hn.C, 0, hn.H, hn.W, L.SP_HEAD, 0, 0, 0, ctx["out"], params["final_conv.3.weight"],
                              red_arena[ho:ho + N * (hn.C + 1)], grads["final_conv.3.weight"], grads["final_conv.3.bias"]))
 

@@ -14,6 +14,8 @@ that `tools/` can A/B schedules on one box without editing the package.  libmris
                        conv_igemm kernels (A/B of csrc/conv_ring.hip inside the training step)
   MRISR_NO_UP_FUSED    1: the decoder's 1x1 conv + bilinear x2 + statistics run as two launches (mrisr_conv_forward at low
                        resolution + mrisr_upsample2_stats) instead of csrc/up_fused.hip
+  MRISR_NO_ONEPASS     1: every GroupNorm backward runs as two launches (reduce + apply) instead of the one-pass kernel with the
+                       in-kernel image barrier (csrc/norm.hip: act_bwd_onepass_kernel)
   MRISR_FORCE_DP       1: bench.py / scripts wrap the model in DataParallel even at world size 1 (rehearses the RCCL path)
 """
 from __future__ import annotations
@@ -43,6 +45,7 @@ class Tuning:
     force_dp: bool
     no_ring: bool
     no_up_fused: bool
+    no_onepass: bool
 
 
 def _read() -> Tuning:
@@ -56,6 +59,7 @@ def _read() -> Tuning:
         force_dp=_int("MRISR_FORCE_DP", 0) == 1,
         no_ring=_int("MRISR_NO_RING", 0) == 1,
         no_up_fused=_int("MRISR_NO_UP_FUSED", 0) == 1,
+        no_onepass=_int("MRISR_NO_ONEPASS", 0) == 1,
     )
 
 

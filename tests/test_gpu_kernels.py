@@ -468,6 +468,80 @@ def test_act_backward(dt, mode):
     assert U.relerr(dbet.cpu(), br.grad) <= tol
 
 
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("case", ["one_block", "many_blocks", "two_consumers", "tail_block", "wide"])
+def test_act_backward_onepass(dt, case):
+    """mrisr_act_bwd_onepass (csrc/norm.hip: act_bwd_onepass_kernel, in-kernel image barrier): GroupNorm + LeakyReLU backward
+    of a node with plain consumers of its own geometry in ONE launch, against autograd of F.group_norm + F.leaky_relu
+    (unet_model.py:30-31) and against the two-pass kernels on the same operands.  many_blocks: 64 blocks per image, 6 images
+    (the barrier is crossed by many blocks on different XCDs); two_consumers: skip concat window (c_off) + a second plain
+    consumer; tail_block: the pixel count is not a multiple of the block's; wide: 64 channel vectors per pixel."""
+    n, c, h, w, two = {"one_block": (2, 32, 8, 32, False), "many_blocks": (6, 64, 128, 128, False),
+                       "two_consumers": (3, 64, 48, 64, True), "tail_block": (2, 32, 19, 27, False),
+                       "wide": (2, 512, 16, 16, True)}[case]
+    x = rnd(n, c, h, w, seed=140)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=141), 0.1 * rnd(c, seed=142)
+    scale, shift, mr = _gn_forward_state(x, gamma, beta, dt)
+    xr = U.rounded(x, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    act = F.leaky_relu(F.group_norm(xr, 8, gr, br, 1e-5), 0.2)
+    da = rnd(n, c + 8, h, w, seed=143)
+    loss = (act * U.rounded(da, dt)[:, 8:]).sum()
+    cons = [(da, c + 8, 8)]
+    if two:
+        db = rnd(n, c, h, w, seed=144)
+        loss = loss + (act * U.rounded(db, dt)).sum()
+        cons.append((db, c, 0))
+    loss.backward()
+    carr, keep = (L.Consumer * 2)(), []
+    for i, (d, ctot, coff) in enumerate(cons):
+        dd = U.nhwc(d, dt)
+        keep.append(dd)
+        carr[i].da, carr[i].C_total, carr[i].c_off, carr[i].H, carr[i].W = dd.data_ptr(), ctot, coff, h, w
+        carr[i].spatial, carr[i].off_y, carr[i].off_x, carr[i].weight_mode = L.SP_NONE, 0, 0, 0
+    assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, h, w, c) == 1
+    xd, gdev = U.nhwc(x, dt), gamma.to(U.DEV)
+    count = float((c // 8) * h * w)
+
+    def run(onepass):
+        red = torch.zeros(n * c * 2 * L.load().mrisr_act_bwd_onepass_slots(), device=U.DEV)
+        arrive = torch.zeros(n * L.load().mrisr_act_bwd_onepass_barrier_words(), dtype=torch.int32, device=U.DEV)
+        dgam, dbet = torch.zeros(c, device=U.DEV), torch.zeros(c, device=U.DEV)
+        dx = torch.full_like(xd, float("nan"))
+        fin = L.GnBwdFin(red.data_ptr(), gdev.data_ptr(), mr.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), None, None, None,
+                         count, 0.0, 8)
+        if onepass:
+            L.call("mrisr_act_bwd_onepass", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), len(cons), carr,
+                   red.data_ptr(), arrive.data_ptr(), C.byref(fin), dx.data_ptr(), n, h, w, c, U.stream())
+        else:
+            L.call("mrisr_act_bwd_reduce", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), len(cons), carr,
+                   None, None, red.data_ptr(), None, n, h, w, c, 8, U.stream())
+            L.call("mrisr_act_bwd_apply_fused", dt, xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), len(cons), carr, None,
+                   None, C.byref(fin), dx.data_ptr(), n, h, w, c, U.stream())
+        torch.cuda.synchronize()
+        return U.nchw(dx), dgam.cpu(), dbet.cpu(), arrive.cpu()
+
+    dx1, dg1, db1, arrive = run(True)
+    assert torch.isfinite(dx1).all(), "a block gave up waiting at the image barrier"
+    nvec = c // 8
+    blocks = -(-(h * w) // ((256 // nvec) * 8))
+    words = arrive.view(n, -1)
+    assert (words[:, 0:256:16].sum(1) == blocks).all() and (words[:, 256] == min(blocks, 16)).all()     # everybody was counted
+    tol = 2e-2
+    assert U.relerr(dx1, xr.grad) <= tol
+    assert U.relerr(dg1, gr.grad) <= tol
+    assert U.relerr(db1, br.grad) <= tol
+    dx2, dg2, db2, _ = run(False)
+    # same arithmetic per element; the per-(n,c) sums are float atomics in both (order differs): storage-rounding agreement
+    assert U.relerr(dx1, dx2) <= 4e-3
+    assert U.relerr(dg1, dg2) <= 1e-4 and U.relerr(db1, db2) <= 1e-4
+    # nodes that do not qualify are refused, not mis-computed
+    carr[0].off_x = 1
+    assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, h, w, c) == 0
+    carr[0].off_x = 0
+    assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, 512, 512, 32) == 0      # 512 blocks per image
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("mode", ["same", "same2", "pad", "pool", "pool+skip"])
 @pytest.mark.parametrize("in_kernel_finalize", [False, True])
