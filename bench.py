@@ -34,7 +34,7 @@ if REPO not in sys.path:
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_TBPS = 8.0                                                     # HBM3E spec peak, same guide (6.3 TB/s measured achievable)
 # entry point of a bandwidth-bound launch -> substring of the kernel symbol rocprofv3 / profiles/pmc_traffic.json report
-ENTRY_KERNEL = {"mrisr_act_bwd_reduce": "act_bwd_reduce_kernel", "mrisr_act_bwd_apply_fused": "act_bwd_apply_fused_kernel",
+ENTRY_KERNEL = {"mrisr_act_bwd_onepass": "act_bwd_onepass_kernel", "mrisr_act_bwd_reduce": "act_bwd_reduce_kernel", "mrisr_act_bwd_apply_fused": "act_bwd_apply_fused_kernel",
                 "mrisr_act_bwd_apply_fused_unshuffle": "act_bwd_unshuffle_window_kernel", "mrisr_act_bwd_apply": "act_bwd_apply_kernel",
                 "mrisr_norm_pool2": "norm_pool2_kernel", "mrisr_norm_upsample2": "norm_upsample2_kernel",
                 "mrisr_norm_blend": "norm_blend_kernel", "mrisr_upsample2_stats": "upsample2_stats_kernel",
@@ -398,7 +398,7 @@ def main():
                                    "timing": f"the dominant kernel is picked among the live-timed CONVOLUTION kernels; HIP events on the launch stream, separate pass of {timed_steps} steps "
                                              f"({timed_elapsed / timed_steps * 1e3:.3f} ms/step instrumented), ONE stream, "
                                              "every persistent kernel sized for the whole chip (the headline region runs "
-                                             "the weight gradients on a second stream, each kind on half the CUs); a "
+                                             "the weight gradients on a second stream sized for 3/8 of the CUs); a "
                                              "conv_wgrad entry = the weight-gradient kernel + its split-K reduce kernel timed "
                                              "as one unit; rocprofv3 counterpart: "
                                              "profiles/r03_step_kernel_stats_single_stream.csv"}

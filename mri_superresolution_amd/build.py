@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "mrisr")
 LIB = os.path.join(HERE, "libmrisr.so")
-SOURCES = ["api.cpp", "conv_fwd.hip", "conv_ring.hip", "conv_pc.hip", "conv_wgrad.hip", "conv_wgrad_rows.hip", "norm.hip", "up_fused.hip", "head_stem.hip", "loss.hip", "optim.hip", "vgg.hip", "image.hip"]
+SOURCES = ["api.cpp", "conv_fwd.hip", "conv_ring.hip", "conv_pc.hip", "conv1x1.hip", "conv_wgrad.hip", "conv_wgrad_rows.hip", "norm.hip", "up_fused.hip", "head_stem.hip", "loss.hip", "optim.hip", "vgg.hip", "image.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # conv_fwd.hip: no SLP vectorisation - it turns the epilogue's statistics into v_pk_*_f32 ops plus register shuffles, and

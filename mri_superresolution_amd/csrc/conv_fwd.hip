@@ -1378,6 +1378,9 @@ int launch_conv_ring(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t
 // conv_pc.hip: producer / consumer waves (GroupNorm or stored sources, 128-channel output blocks)
 bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p);
 int launch_conv_pc(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
+// conv1x1.hip: 1x1 convolutions as a plain GEMM
+bool conv1x1_gemm_eligible(const mrisr_conv_desc* d, const ConvParams& p);
+int launch_conv1x1_gemm(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
 
 // every source stored as-is and a plain (single / concat) loader: the halo tile can go global -> LDS by LDS-DMA
 static bool conv_dma_halo(const ConvParams& p, int spatial) {
@@ -1490,6 +1493,8 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
         snprintf(out, n, "conv_ring_kernel<%s,2,4>", t);
     } else if (conv_pc_eligible(d, p)) {
         snprintf(out, n, "conv_pc_kernel<%s,%d>", t, d->src[0].mode == MRISR_SRC_NORM ? 1 : 0);
+    } else if (conv1x1_gemm_eligible(d, p)) {
+        snprintf(out, n, "conv1x1_gemm_kernel<%s,%d>", t, d->src[0].mode == MRISR_SRC_NORM ? 1 : 0);
     } else {
         const int BN = conv_choose_bn(d->Cout);
         const size_t wimg = (size_t)d->ksize * d->ksize * BN * kRowBytes;
@@ -1512,6 +1517,7 @@ extern "C" int mrisr_conv_forward(const mrisr_conv_desc* d, void* stream) {
     if (d->stats && (d->groups <= 0 || d->Cout % d->groups)) MRISR_FAIL(MRISR_E_SHAPE, "conv_forward: Cout %d not divisible by groups %d", d->Cout, d->groups);
     if (conv_ring_eligible(d, p)) return launch_conv_ring(d, p, (hipStream_t)stream);
     if (conv_pc_eligible(d, p)) return launch_conv_pc(d, p, (hipStream_t)stream);
+    if (conv1x1_gemm_eligible(d, p)) return launch_conv1x1_gemm(d, p, (hipStream_t)stream);
     // square 16 x 16 output tiles (324-pixel halo, 18-pixel rows) instead of 8 x 32 (340, 34): the kernels are bound by the
     // operand bytes they stage (profiles/NOTES.md R2-13/14).  32 -> 32 at 512^2: 167 -> 130 us, 64 -> 32 / 32 -> 64: 3-5 %, wide
     // layers +-2 % each, the training step -0.8 % with every 3x3 layer on 16 x 16 (A/B on one box).  The weight-gradient

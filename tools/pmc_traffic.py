@@ -31,6 +31,9 @@ def demangle_conv(name):
     m = re.match(r"_Z16conv_ring_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)ELb[01]EEv10RingParams", name)
     if m:      # (the two statistics variants are one bench entry)
         return f"conv_ring_kernel<{_t(m.group(1))},{m.group(2)},{m.group(3)}>"
+    m = re.match(r"_Z14conv_pc_kernelI(DF16b|DF16_)Lb([01])ELb[01]EEv10ConvParams", name)
+    if m:      # (the two statistics variants are one bench entry)
+        return f"conv_pc_kernel<{_t(m.group(1))},{m.group(2)}>"
     m = re.match(r"_Z22conv_wgrad_rows_kernelI(DF16b|DF16_)Li(\d)ELi(\d)ELb([01])EEv10ConvParams", name)
     if m:
         return f"conv_wgrad_rows_kernel<{_t(m.group(1))},{m.group(2)},{m.group(3)},{m.group(4)}>"
