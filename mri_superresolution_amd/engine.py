@@ -380,9 +380,10 @@ class UNetEngine:
             d.wpacked = self._packed[(layer.name, dt, 0)].data_ptr()
             d.wpacked_ring = L.ptr(self._packed.get((layer.name, dt, 0, "ring")))
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None
-            if layer.post_up and es == 2 and layer.cin % 32 == 0 and layer.cout % 64 == 0 and not TUNING.no_up_fused:
-                # 16-bit storage: conv1x1 at low resolution + bilinear x2 + statistics in ONE launch (csrc/up_fused.hip);
-                # the low-resolution tensor never goes to HBM
+            if layer.post_up and es == 2 and layer.cin % 32 == 0 and layer.cout % 64 == 0 and TUNING.up_fused:
+                # (A/B switch) conv1x1 at low resolution + bilinear x2 + statistics in ONE launch (csrc/up_fused.hip): the
+                # low-resolution tensor never goes to HBM, but every output tile recomputes its 10 x 10 low-resolution patch and
+                # re-reads it per 64 output channels - the GEMM of csrc/conv1x1.hip + mrisr_upsample2_stats is faster
                 sn = layer.srcs[0].node
                 fl = 2.0 * N * vh * vw * layer.cin * layer.cout
                 call = lambda: L.call("mrisr_up_conv1x1_fused", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),

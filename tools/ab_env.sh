@@ -1,5 +1,5 @@
 #!/bin/bash
-# In-step A/B of a host-side tuning switch on ONE box: tools/ab_env.sh MRISR_NO_UP_FUSED  -> bench.py alternating VAR unset / VAR=1
+# In-step A/B of a host-side tuning switch on ONE box: tools/ab_env.sh MRISR_NO_ONEPASS  -> bench.py alternating VAR unset / VAR=1
 var=$1
 for i in 1 2 3; do
   for v in 0 1; do
