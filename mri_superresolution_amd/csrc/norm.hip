@@ -19,11 +19,15 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float
     if (idx >= N * C) return;
     const int n = idx / C, c = idx - n * C;
     const int gs = C / groups, g = c / gs;
+    // the 16 slot pairs as 16-byte loads, all in flight at once (this launch sits between every two convolutions of the
+    // forward pass: its latency is paid 20 times per step), summed in slot order
+    typedef __attribute__((ext_vector_type(2))) double f64x2;
+    f64x2 v[MRISR_STAT_SLOTS];
+#pragma unroll
+    for (int k = 0; k < MRISR_STAT_SLOTS; ++k) v[k] = *reinterpret_cast<const f64x2*>(stats + ((size_t)(k * N + n) * groups + g) * 2);
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < MRISR_STAT_SLOTS; ++k) {
-        s += stats[((size_t)(k * N + n) * groups + g) * 2];
-        ss += stats[((size_t)(k * N + n) * groups + g) * 2 + 1];
-    }
+#pragma unroll
+    for (int k = 0; k < MRISR_STAT_SLOTS; ++k) { s += v[k][0]; ss += v[k][1]; }
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0) var = 0;
