@@ -357,7 +357,6 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
     const bool has_br = p.bias != nullptr || p.relu_out != 0;
-    const bool ps = p.out_mode == MRISR_OUT_PIXEL_SHUFFLE2;
     const int gs = p.groups > 0 ? p.Cout / p.groups : 4;
     // GroupNorm partial sums per lane: a group spans >= 16 channels here (host-checked), i.e. the quad pairs {0,1} and {2,3}
     // of a fragment each lie in one group
@@ -375,14 +374,6 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         char* obase = (char*)p.out + e0 * sizeof(T);
         int lh_e = lh;
         asm volatile("" : "+v"(lh_e));
-        // pixel-shuffled output [N][2H][2W][Cout / 4]: this lane's rows 2 (ty0 + py) + dy with dy = its half-wave
-        const int C4 = p.Cout >> 2;
-        const unsigned ps_dx = (unsigned)C4 * 2u;
-        char* ps_base = (char*)p.out + (((size_t)(n * 2 * p.H + 2 * ty0) * (2 * p.W) + 2 * tx0) * C4 + (bn0 >> 2)) * sizeof(T);
-        unsigned ps_off[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-            ps_off[mi] = (unsigned)(((2 * (MI * wave + mi) + lh_e) * (2 * p.W) + 2 * lr) * C4) * 2u;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int py = MI * wave + mi, px = lr;
@@ -425,30 +416,13 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                     cv.b = t4_t{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
                     packed[q] = cv.u;
                 }
-                if (!ps) {
 #pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        const u32x2 a = packed[q], b = packed[q + 1];
-                        auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-                        const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-                        gstore(obase + loff + (ni * 32 + 8 * q) * 2, o);
-                    }
-                } else {
-                    // PixelShuffle(2) (unet_model.py:102): cout 4c + 2dy + dx -> pixel (2y + dy, 2x + dx), channel c.  A lane holds
-                    // the four sub-pixels (packed[q] = {dy 0: dx 0,1 | dy 1: dx 0,1}) of channels c = 8 ni + 2q + lh; after the
-                    // exchange the lower half-wave owns dy = 0 and the upper one dy = 1, each with both channels of every pair:
-                    // 8 consecutive channels per (ni, dx) = one 16-byte store
-                    unsigned e[4], o4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        auto r = __builtin_amdgcn_permlane32_swap(packed[q][0], packed[q][1], false, false);
-                        e[q] = __builtin_amdgcn_perm(r[1], r[0], 0x05040100u);      // dx = 0: channels 2q, 2q + 1
-                        o4[q] = __builtin_amdgcn_perm(r[1], r[0], 0x07060302u);     // dx = 1
-                    }
-                    char* pb = ps_base + ps_off[mi] + ni * 16;
-                    gstore(pb, u32x4{e[0], e[1], e[2], e[3]});
-                    gstore(pb + ps_dx, u32x4{o4[0], o4[1], o4[2], o4[3]});
+                for (int q = 0; q < 4; q += 2) {
+                    const u32x2 a = packed[q], b = packed[q + 1];
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    gstore(obase + loff + (ni * 32 + 8 * q) * 2, o);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -551,7 +525,7 @@ bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p) {
 #endif
     if (!d->wpacked_ring) return false;
     if (d->dtype == MRISR_F32 || d->ksize != 3 || d->Cin % 16 || d->Cout % kPcBN) return false;
-    if ((d->out_mode != MRISR_OUT_PLAIN && d->out_mode != MRISR_OUT_PIXEL_SHUFFLE2) || d->relu_mask || d->combine != MRISR_COMBINE_CONCAT) return false;
+    if (d->out_mode != MRISR_OUT_PLAIN || d->relu_mask || d->combine != MRISR_COMBINE_CONCAT) return false;
     if (d->nsrc < 1 || d->nsrc > 2) return false;
     for (int i = 0; i < d->nsrc; ++i) {
         if (d->src[i].spatial != MRISR_SP_NONE) return false;

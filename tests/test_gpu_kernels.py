@@ -144,8 +144,7 @@ def test_conv_ring_raw_source(dt, case):
 
 
 @pytest.mark.parametrize("dt", [L.BF16, L.F16])
-@pytest.mark.parametrize("case", ["norm", "norm_multi_tile", "norm_concat_pad", "raw_bias_relu", "raw_odd_items", "half_chip",
-                                  "pixel_shuffle_bias"])
+@pytest.mark.parametrize("case", ["norm", "norm_multi_tile", "norm_concat_pad", "raw_bias_relu", "raw_odd_items", "half_chip"])
 def test_conv_pc_producer_consumer(dt, case):
     """csrc/conv_pc.hip (staging waves + MFMA waves, 8 x 32 x 128-channel items of 16 input channels): launches that
     qualify - 3x3, plain sources all GroupNorm-activated or all stored, Cout a multiple of 128, Cin of 16, planes of whole
@@ -153,16 +152,13 @@ def test_conv_pc_producer_consumer(dt, case):
     tiles per workgroup with an image change inside a range (statistics flushed per image); norm_concat_pad: skip || up-path
     concat with the second source smaller and offset (unet_model.py:86-92; chunks switch source at 48 channels);
     raw_bias_relu: stored source, bias + ReLU epilogue, no statistics (input-gradient / VGG form); raw_odd_items: an odd item
-    count per workgroup (the staging loop's padding half); half_chip: grid sized by cu_limit; pixel_shuffle_bias: the
-    PixelShuffleUp conv (unet_model.py:101-102: bias, output stored shuffled, statistics over groups of 16 conv channels)."""
+    count per workgroup (the staging loop's padding half); half_chip: grid sized by cu_limit."""
     n, cins, cout, h, w = {"norm": (8, (64,), 128, 64, 96), "norm_multi_tile": (13, (32,), 256, 40, 96),
                            "norm_concat_pad": (8, (48, 32), 128, 64, 96), "raw_bias_relu": (8, (144,), 256, 64, 96),
-                           "raw_odd_items": (3, (176,), 128, 40, 32), "half_chip": (8, (64,), 128, 64, 96),
-                           "pixel_shuffle_bias": (8, (64,), 256, 64, 96)}[case]
+                           "raw_odd_items": (3, (176,), 128, 40, 32), "half_chip": (8, (64,), 128, 64, 96)}[case]
     cin = sum(cins)
     wt = rnd(cout, cin, 3, 3, seed=52, scale=0.1)
-    norm = case.startswith("norm") or case in ("half_chip", "pixel_shuffle_bias")
-    shuffle = case == "pixel_shuffle_bias"
+    norm = case.startswith("norm") or case == "half_chip"
     srcs = []
     for i, c in enumerate(cins):
         hs, ws, off = (h, w, (0, 0)) if i == 0 else (h - 3, w - 5, (1, 2))
@@ -172,11 +168,9 @@ def test_conv_pc_producer_consumer(dt, case):
             srcs.append(U.SrcSpec(x, L.SRC_NORM, L.SP_NONE, sc, sh, off=off))
         else:
             srcs.append(U.SrcSpec(x, off=off))
-    bias = rnd(cout, seed=57) if case in ("raw_bias_relu", "pixel_shuffle_bias") else None
+    bias = rnd(cout, seed=57) if case == "raw_bias_relu" else None
     ran = []
     kw = dict(bias=bias, with_stats=case != "raw_bias_relu", variant=ran)
-    if shuffle:
-        kw["out_mode"] = L.OUT_PIXEL_SHUFFLE2
     if case in ("half_chip", "raw_odd_items"):
         kw["cu_limit"] = 128 if case == "half_chip" else 16
     if case == "raw_bias_relu":
@@ -187,7 +181,7 @@ def test_conv_pc_producer_consumer(dt, case):
     if case == "raw_bias_relu":
         ref = F.relu(ref)
     assert torch.isfinite(out).all()
-    assert U.relerr(out, F.pixel_shuffle(ref, 2) if shuffle else ref) <= (TOL_NORM[dt] if norm else TOL_OUT[dt])
+    assert U.relerr(out, ref) <= (TOL_NORM[dt] if norm else TOL_OUT[dt])
     if kw["with_stats"]:
         o = ref.view(n, 8, cout // 8, h, w).double()      # (the kernel sums its fp32 accumulators, before the storage rounding)
         assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-4 * o.abs().sum((2, 3, 4)).max().item())
