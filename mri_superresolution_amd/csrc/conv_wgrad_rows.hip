@@ -386,27 +386,35 @@ __global__ __launch_bounds__(kWrThreads, 2) void conv_wgrad_rows_kernel(const Co
         }
 }
 
-// Second stage: dw[co][tap][ci] += sum over the split-K slabs (thread = one accumulator element of the slab layout; the row
-// parts of one fragment pair land on the same element of dw)
-constexpr int kWrRedChunk = 8;
+// Second stage: dw[co][tap][ci] += sum over the split-K slabs and the row parts of a fragment pair.  Thread = one element of dw
+// (fragment pair, tap, register, lane); blockIdx.y = chunk of kWrRedChunk slabs.  With one chunk the thread is the only writer
+// of its element: a plain read-modify-write instead of a float atomic (the version with 8 slabs per chunk and one thread per
+// SLAB element spent 18 us per launch on 0.2 GB: 0.9 TB/s, three scattered atomics per element).
+constexpr int kWrRedChunk = 24;
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk,
                                                                 int ksplit, int Cout, int Cin, int nco, int nci) {
-    const int per_blk = 4 * kWrAcc;
-    const size_t total = (size_t)nblk * per_blk;
+    const int npairs = nco * nci, nparts = 4 / npairs;
+    const int per_blk = 4 * kWrAcc, per_out = npairs * kWrAcc;
+    const size_t total = (size_t)nblk * per_blk, total_out = (size_t)nblk * per_out;
     const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    if (idx >= total_out) return;
+    const int blk = idx / per_out, rem = idx - (size_t)blk * per_out;
+    const int pair = rem / kWrAcc, ar = (rem - pair * kWrAcc) >> 6, lane = rem & 63;
+    const float* src = ws + (size_t)blk * per_blk + (size_t)pair * kWrAcc + (ar << 6) + lane;
     float s = 0.f;
-    const int k0 = blockIdx.y * kWrRedChunk;
-#pragma unroll
-    for (int k = 0; k < kWrRedChunk; ++k)
-        if (k0 + k < ksplit) s += ws[(size_t)(k0 + k) * total + idx];
-    const int blk = idx / per_blk, rem = idx - (size_t)blk * per_blk;
-    const int wave = rem / kWrAcc, ar = (rem - wave * kWrAcc) >> 6, lane = rem & 63;
+    const int k0 = blockIdx.y * kWrRedChunk, k1 = min(k0 + kWrRedChunk, ksplit);
+    for (int part = 0; part < nparts; ++part) {
+        const float* sp = src + (size_t)part * npairs * kWrAcc;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) s += sp[(size_t)k * total];
+    }
     const int a = ar >> 4, r = ar & 15, lr = lane & 31, lh = lane >> 5;
     const int ncib = Cin / (32 * nci), cib = blk % ncib, cob = blk / ncib;
-    const int pair = wave % (nco * nci), fo = pair / nci, fi = pair % nci;
+    const int fo = pair / nci, fi = pair % nci;
     const int co = cob * 32 * nco + fo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ci = cib * 32 * nci + fi * 32 + lr;
-    if (s != 0.f) atomic_add_f32(dw + ((size_t)co * 9 + a) * Cin + ci, s);
+    float* d = dw + ((size_t)co * 9 + a) * Cin + ci;
+    if (gridDim.y == 1) *d += s;
+    else if (s != 0.f) atomic_add_f32(d, s);
 }
 
 #ifndef MRISR_KERNEL_ONLY
@@ -473,7 +481,7 @@ static int launch_wgrad_rows_t(ConvParams& p, size_t ws_floats, hipStream_t s) {
     MRISR_CHECK_LAUNCH("conv_wgrad(rows)");
     if (p.wsp) {
         const size_t total = need / ksplit;
-        wgrad_rows_reduce_kernel<<<dim3((unsigned)((total + 255) / 256), ceil_div(ksplit, kWrRedChunk)), 256, 0, s>>>(p.wsp, p.dw, nblk, ksplit, p.Cout, p.Cin, NCO, NCI);
+        wgrad_rows_reduce_kernel<<<dim3((unsigned)((total / (4 / (NCO * NCI)) + 255) / 256), ceil_div(ksplit, kWrRedChunk)), 256, 0, s>>>(p.wsp, p.dw, nblk, ksplit, p.Cout, p.Cin, NCO, NCI);
         MRISR_CHECK_LAUNCH("conv_wgrad(rows reduce)");
     }
     return MRISR_OK;

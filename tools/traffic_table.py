@@ -14,11 +14,14 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else pmc.get("steps_profiled", 8)
 
 
 def canon(name):
-    m = re.match(r"_Z\d+(conv_igemm_kernel|conv_wgrad_kernel)I(DF16b|DF16_|f)((?:L[ib]\d+E)+)", name)
+    """Base kernel name: rocprofv3 reports some instantiations mangled, some with a garbled template list, and the PMC and
+    kernel-trace outputs disagree on which - the template variants of a kernel are therefore ONE row here."""
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"_Z(\d+)", name)
     if m:
-        t = {"DF16b": "bf16", "DF16_": "f16", "f": "f32"}[m.group(2)]
-        return f"{m.group(1)}<{t}," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
-    return name.split("(")[0]
+        n = int(m.group(1))
+        return name[m.end():m.end() + n]
+    return re.split(r"[<(]", name)[0].strip()
 
 
 dur = {}
@@ -26,23 +29,25 @@ for r in csv.DictReader(open(sys.argv[2])):
     k = canon(r["Name"])
     c, t = dur.get(k, (0, 0))
     dur[k] = (c + int(r["Calls"]), t + int(r["TotalDurationNs"]))
-rows = []
+agg = {}
 for name, v in pmc["kernels"].items():
-    k = canon(name) if not name.startswith("conv_") else name
+    k = canon(name)
+    b, n = agg.get(k, (0.0, 0.0))
+    agg[k] = (b + v["launches"] / steps * v["hbm_bytes_per_launch"], n + v["launches"] / steps)
+rows = []
+for k, (b, n) in agg.items():
     calls, tot = dur.get(k, (0, 0))
-    b = v["launches"] / steps * v["hbm_bytes_per_launch"]
-    us = tot / steps / 1e3 if calls else 0.0
-    rows.append((b, us, k, v["launches"] / steps))
+    rows.append((b, tot / steps / 1e3 if calls else 0.0, k, n))
 rows.sort(reverse=True)
-print(f"# csrc {pmc['csrc_sha16']}; L2-side bytes (FETCH_SIZE x2 + WRITE_SIZE) per step, kernel time per step (one stream, every kernel alone)")
-print(f"{'kernel':58s} {'launches':>8s} {'GB/step':>8s} {'us/step':>8s} {'TB/s':>6s}")
+print(f"# csrc {pmc['csrc_sha16']}; HBM-side bytes (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) per step, kernel time per step")
+print("# (one stream, every kernel alone on the whole chip); the template variants of a kernel are summed")
+print(f"{'kernel':44s} {'launches':>8s} {'GB/step':>8s} {'us/step':>8s} {'TB/s':>6s}")
 tot = {"conv": [0, 0], "elementwise": [0, 0]}
 for b, us, k, n in rows:
-    kind = "conv" if k.startswith("conv_") or "wgrad_reduce" in k else "elementwise"
-    k = re.sub(r"^_Z\d+|^void ", "", k)
+    kind = "conv" if k.startswith("conv") or "wgrad" in k or k.startswith("up1x1") else "elementwise"
     tot[kind][0] += b
     tot[kind][1] += us
     if b > 2e7:
-        print(f"{k[:58]:58s} {n:8.1f} {b / 1e9:8.2f} {us:8.1f} {b / us / 1e6 if us else 0:6.2f}")
+        print(f"{k[:44]:44s} {n:8.1f} {b / 1e9:8.2f} {us:8.1f} {b / us / 1e6 if us else 0:6.2f}")
 for kind, (b, us) in tot.items():
     print(f"# {kind}: {b / 1e9:.2f} GB/step in {us / 1e3:.2f} ms = {b / us / 1e6:.2f} TB/s")
