@@ -291,6 +291,13 @@ int mrisr_ssim_l1_forward(const float* a, const float* b, double* sums, float* c
 int mrisr_ssim_l1_backward(const float* a, const float* b, const float* coef, const double* sums,
                            const float* gscale, float l1_w, float ssim_w, float* da, int N, int H,
                            int W, float sigma, void* stream);
+/* the same two with the window size of utils/losses.py:27 (`window_size`: odd, 3 .. 15; the entries above are these with 11).
+ * The gradient w.r.t. the SECOND image (SSIM and L1 are symmetric): swap a and b in both calls.                           */
+int mrisr_ssim_l1_forward_win(const float* a, const float* b, double* sums, float* coef, int N, int H, int W,
+                              float val_range, float sigma, int window_size, void* stream);
+int mrisr_ssim_l1_backward_win(const float* a, const float* b, const float* coef, const double* sums,
+                               const float* gscale, float l1_w, float ssim_w, float* da, int N, int H, int W,
+                               float sigma, int window_size, void* stream);
 
 /* CombinedLoss scalar without the perceptual term (utils/losses.py:200-226): out[0] = l1_w*L1 +
  * ssim_w*(1-clamp(SSIM,0,1)), out[1] = L1 mean, out[2] = SSIM mean, out[3+n] = per-sample SSIM.   */

@@ -104,6 +104,8 @@ SIGNATURES = {
     "mrisr_head_backward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mrisr_ssim_l1_forward": (_i, [_fp, _fp, _dp, _fp, _i, _i, _i, _f, _f, _vp]),
     "mrisr_ssim_l1_backward": (_i, [_fp, _fp, _fp, _dp, _fp, _f, _f, _fp, _i, _i, _i, _f, _vp]),
+    "mrisr_ssim_l1_forward_win": (_i, [_fp, _fp, _dp, _fp, _i, _i, _i, _f, _f, _i, _vp]),
+    "mrisr_ssim_l1_backward_win": (_i, [_fp, _fp, _fp, _dp, _fp, _f, _f, _fp, _i, _i, _i, _f, _i, _vp]),
     "mrisr_loss_finalize": (_i, [_dp, _i, _i, _i, _f, _f, _fp, _vp]),
     "mrisr_vgg_input_channels": (_i, []),
     "mrisr_vgg_input_forward": (_i, [_i, _fp, _vp, _sz, _vp]),
@@ -122,7 +124,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 302      # mrisr_version() of the library these struct layouts and signatures belong to
+ABI_VERSION = 303      # mrisr_version() of the library these struct layouts and signatures belong to
 
 
 def load():

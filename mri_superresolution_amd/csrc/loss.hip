@@ -8,21 +8,21 @@
 // and d(sum S)/dx = G(dS/dmu1) + 2x G(dS/dE[x^2]) + y G(dS/dE[xy])   (G = the same zero-padded blur).
 #include "common.h"
 
-constexpr int kWin = 11, kHalo = 5;
-constexpr int kTW = 32, kTH = 8;                   // output tile
-constexpr int kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;   // 42 x 18
+constexpr int kMaxWin = 15;                        // odd window sizes 3 .. 15 (the reference's default and only caller value: 11)
+constexpr int kTW = 32, kTH = 8;                   // output tile of the backward kernel
 
-struct GaussWin { float g[kWin]; };
+struct GaussWin { float g[kMaxWin]; };
 
-static GaussWin make_window(float sigma) {   // losses.py:10-18 in fp32
+static GaussWin make_window(float sigma, int win) {   // losses.py:10-18 in fp32
     GaussWin w;
     float sum = 0.f;
-    for (int i = 0; i < kWin; ++i) {
-        const float c = (float)(i - kWin / 2);
+    for (int i = 0; i < kMaxWin; ++i) w.g[i] = 0.f;
+    for (int i = 0; i < win; ++i) {
+        const float c = (float)(i - win / 2);
         w.g[i] = expf(-(c * c) / (2.0f * sigma * sigma));
         sum += w.g[i];
     }
-    for (int i = 0; i < kWin; ++i) w.g[i] /= sum;
+    for (int i = 0; i < win; ++i) w.g[i] /= sum;
     return w;
 }
 
@@ -30,10 +30,11 @@ static GaussWin make_window(float sigma) {   // losses.py:10-18 in fp32
 // 4 neighbouring outputs share 14 inputs, so the LDS reads per output drop from 104 (one output per thread, 32 x 8
 // tile) to 27 and the halo overhead from 2.95x to 1.72x.
 constexpr int kFT = 32;                              // forward tile edge
-constexpr int kFL = kFT + 2 * kHalo;                 // 42
+template <int kWin>
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           double* __restrict__ sums, float* __restrict__ coef, int N,
                                                           int H, int W, float c1, float c2, const GaussWin win) {
+    constexpr int kHalo = kWin / 2, kFL = kFT + 2 * kHalo;     // 42 for the 11-tap window
     __shared__ float ta[kFL][kFL + 2], tb[kFL][kFL + 2];
     __shared__ float hz[5][kFL][kFT + 1];            // horizontally blurred x, y, xx, yy, xy
     __shared__ float part[4][2];
@@ -113,21 +114,41 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(const float* __restric
     if (t < 2) atomic_add_f64(&sums[(size_t)n * 2 + t], (double)(part[0][t] + part[1][t] + part[2][t] + part[3][t]));
 }
 
-extern "C" int mrisr_ssim_l1_forward(const float* a, const float* b, double* sums, float* coef, int N, int H, int W,
-                                     float val_range, float sigma, void* stream) {
+template <int WIN>
+static void launch_ssim_fwd(dim3 grid, hipStream_t s, const float* a, const float* b, double* sums, float* coef, int N, int H, int W,
+                            float c1, float c2, float sigma) {
+    ssim_l1_fwd_kernel<WIN><<<grid, 256, 0, s>>>(a, b, sums, coef, N, H, W, c1, c2, make_window(sigma, WIN));
+}
+#define MRISR_SSIM_WIN_SWITCH(win, CALL) \
+    switch (win) { case 3: CALL(3); break; case 5: CALL(5); break; case 7: CALL(7); break; case 9: CALL(9); break; \
+                   case 11: CALL(11); break; case 13: CALL(13); break; default: CALL(15); break; }
+
+// window_size: odd, 3 .. 15 (losses.py:27's parameter; even sizes change the reference's output size and are refused)
+extern "C" int mrisr_ssim_l1_forward_win(const float* a, const float* b, double* sums, float* coef, int N, int H, int W,
+                                         float val_range, float sigma, int window_size, void* stream) {
     if (!a || !b || !sums) MRISR_FAIL(MRISR_E_ARG, "ssim_l1_forward: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "ssim_l1_forward: N%d H%d W%d", N, H, W);
+    if (window_size < 3 || window_size > kMaxWin || !(window_size & 1)) MRISR_FAIL(MRISR_E_UNSUPPORTED, "ssim_l1_forward: window_size %d (odd, 3..15)", window_size);
     const float c1 = (0.01f * val_range) * (0.01f * val_range), c2 = (0.03f * val_range) * (0.03f * val_range);
     dim3 grid(ceil_div(W, kFT), ceil_div(H, kFT), N);
-    ssim_l1_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, b, sums, coef, N, H, W, c1, c2, make_window(sigma));
+    hipStream_t s = (hipStream_t)stream;
+#define MRISR_CALL(WIN) launch_ssim_fwd<WIN>(grid, s, a, b, sums, coef, N, H, W, c1, c2, sigma)
+    MRISR_SSIM_WIN_SWITCH(window_size, MRISR_CALL)
+#undef MRISR_CALL
     MRISR_CHECK_LAUNCH("ssim_l1_forward");
     return MRISR_OK;
 }
+extern "C" int mrisr_ssim_l1_forward(const float* a, const float* b, double* sums, float* coef, int N, int H, int W,
+                                     float val_range, float sigma, void* stream) {
+    return mrisr_ssim_l1_forward_win(a, b, sums, coef, N, H, W, val_range, sigma, 11, stream);
+}
 
+template <int kWin>
 __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           const float* __restrict__ coef, const double* __restrict__ sums,
                                                           const float* __restrict__ gscale, float l1_w, float ssim_w,
                                                           float* __restrict__ da, int N, int H, int W, const GaussWin win) {
+    constexpr int kHalo = kWin / 2, kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;     // 42 x 18 for the 11-tap window
     __shared__ float tc[3][kLH][kLW + 1];
     __shared__ float hz[3][kLH][kTW + 1];
     const int t = threadIdx.x, n = blockIdx.z;
@@ -190,16 +211,32 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(const float* __restric
     }
 }
 
-extern "C" int mrisr_ssim_l1_backward(const float* a, const float* b, const float* coef, const double* sums,
-                                      const float* gscale, float l1_w, float ssim_w, float* da, int N, int H, int W,
-                                      float sigma, void* stream) {
+template <int WIN>
+static void launch_ssim_bwd(dim3 grid, hipStream_t s, const float* a, const float* b, const float* coef, const double* sums,
+                            const float* gscale, float l1_w, float ssim_w, float* da, int N, int H, int W, float sigma) {
+    ssim_l1_bwd_kernel<WIN><<<grid, 256, 0, s>>>(a, b, coef, sums, gscale, l1_w, ssim_w, da, N, H, W, make_window(sigma, WIN));
+}
+// Gradient w.r.t. the FIRST image; SSIM and L1 are symmetric, so the gradient w.r.t. the second one is this call with the
+// images swapped and `coef` from a forward call with the images swapped.
+extern "C" int mrisr_ssim_l1_backward_win(const float* a, const float* b, const float* coef, const double* sums,
+                                          const float* gscale, float l1_w, float ssim_w, float* da, int N, int H, int W,
+                                          float sigma, int window_size, void* stream) {
     if (!a || !b || !da) MRISR_FAIL(MRISR_E_ARG, "ssim_l1_backward: null pointer");
     if (ssim_w != 0.f && !coef) MRISR_FAIL(MRISR_E_ARG, "ssim_l1_backward: ssim term needs coef");
     if (N <= 0 || H <= 0 || W <= 0 || N > 65535) MRISR_FAIL(MRISR_E_SHAPE, "ssim_l1_backward: N%d H%d W%d", N, H, W);
+    if (window_size < 3 || window_size > kMaxWin || !(window_size & 1)) MRISR_FAIL(MRISR_E_UNSUPPORTED, "ssim_l1_backward: window_size %d (odd, 3..15)", window_size);
     dim3 grid(ceil_div(W, kTW), ceil_div(H, kTH), N);
-    ssim_l1_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, b, coef, sums, gscale, l1_w, ssim_w, da, N, H, W, make_window(sigma));
+    hipStream_t s = (hipStream_t)stream;
+#define MRISR_CALL(WIN) launch_ssim_bwd<WIN>(grid, s, a, b, coef, sums, gscale, l1_w, ssim_w, da, N, H, W, sigma)
+    MRISR_SSIM_WIN_SWITCH(window_size, MRISR_CALL)
+#undef MRISR_CALL
     MRISR_CHECK_LAUNCH("ssim_l1_backward");
     return MRISR_OK;
+}
+extern "C" int mrisr_ssim_l1_backward(const float* a, const float* b, const float* coef, const double* sums,
+                                      const float* gscale, float l1_w, float ssim_w, float* da, int N, int H, int W,
+                                      float sigma, void* stream) {
+    return mrisr_ssim_l1_backward_win(a, b, coef, sums, gscale, l1_w, ssim_w, da, N, H, W, sigma, 11, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ from .. import _lib as L
 VGG_MEAN = [0.485, 0.456, 0.406]
 VGG_STD = [0.229, 0.224, 0.225]
 
-_WINDOW = 11    # the fused kernel is specialised for the 11-tap window every caller uses
+_WINDOW = 11    # the window every caller of the reference uses (the kernels are instantiated for odd sizes 3..15)
 
 
 def gaussian_window(window_size: int, sigma: float):
@@ -50,16 +50,23 @@ def _planes(t: torch.Tensor) -> torch.Tensor:
 _last_sums = None
 
 
-def _sums_key(a, b, sigma, val_range):
-    return (a.data_ptr(), a._version, tuple(a.shape), b.data_ptr(), b._version, float(sigma), float(val_range),
+def _sums_key(a, b, sigma, val_range, win):
+    return (a.data_ptr(), a._version, tuple(a.shape), b.data_ptr(), b._version, float(sigma), float(val_range), int(win),
             L.inplace_epoch, torch.cuda.current_stream().cuda_stream)
+
+
+def _check_window(window_size):
+    """Odd window sizes 3..15 run in the fused kernel.  Even sizes make the reference's F.conv2d(padding=ws//2) maps one pixel
+    larger than the images (losses.py:44-50) - refused rather than imitated."""
+    if not isinstance(window_size, int) or window_size < 3 or window_size > 15 or window_size % 2 == 0:
+        raise NotImplementedError(f"the fused SSIM kernel supports odd window sizes 3..15, got {window_size!r}")
 
 
 class _SSIML1(torch.autograd.Function):
     """kind 0: returns l1_w*L1 + ssim_w*(1-clamp(SSIM,0,1));  kind 1: returns mean SSIM."""
 
     @staticmethod
-    def forward(ctx, img1, img2, l1_w, ssim_w, sigma, val_range, kind, holder, track):
+    def forward(ctx, img1, img2, l1_w, ssim_w, sigma, val_range, kind, holder, track, win=_WINDOW, track2=False):
         a, b = _planes(img1), _planes(img2)
         if a.shape != b.shape:
             raise ValueError(f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
@@ -68,51 +75,67 @@ class _SSIML1(torch.autograd.Function):
         need_grad = bool(track)      # (ctx.needs_input_grad ignores torch.no_grad(): it would save the SSIM maps for nothing)
         st = L.stream_ptr()
         global _last_sums
-        key = _sums_key(a, b, sigma, val_range)
-        if not need_grad and _last_sums is not None and _last_sums[0] == key:
+        key = _sums_key(a, b, sigma, val_range, win)
+        if not need_grad and not track2 and _last_sums is not None and _last_sums[0] == key:
             sums, coef = _last_sums[1], None
         else:
             sums = torch.zeros(planes * 2, dtype=torch.float64, device=a.device)
             coef = torch.empty(3 * planes * h * w, dtype=torch.float32, device=a.device) if (need_grad and ssim_w != 0) else None
             # algorithmic traffic: the two fp32 images once (8 B per pixel) + the three coefficient planes kept
             # for the backward pass when a gradient is wanted
-            L.call("mrisr_ssim_l1_forward", a.data_ptr(), b.data_ptr(), sums.data_ptr(), L.ptr(coef), planes, h, w,
-                   float(val_range), float(sigma), st, nbytes=planes * h * w * (8 + (12 if coef is not None else 0)))
+            L.call("mrisr_ssim_l1_forward_win", a.data_ptr(), b.data_ptr(), sums.data_ptr(), L.ptr(coef), planes, h, w,
+                   float(val_range), float(sigma), int(win), st, nbytes=planes * h * w * (8 + (12 if coef is not None else 0)))
             _last_sums = (key, sums, a, b)
         comp = torch.empty(3 + planes, dtype=torch.float32, device=a.device)
         L.call("mrisr_loss_finalize", sums.data_ptr(), planes, h, w, float(l1_w), float(ssim_w), comp.data_ptr(), st)
         if holder is not None:
             holder.last_components = comp
         ctx.save_for_backward(a, b, coef, sums)
-        ctx.cfg = (float(l1_w), float(ssim_w), float(sigma), kind, planes, h, w)
+        ctx.cfg = (float(l1_w), float(ssim_w), float(sigma), kind, planes, h, w, int(win), float(val_range), bool(track), bool(track2))
         return comp[0].clone() if kind == 0 else comp[2].clone()
 
     @staticmethod
     def backward(ctx, gout):
         a, b, coef, sums = ctx.saved_tensors
-        l1_w, ssim_w, sigma, kind, planes, h, w = ctx.cfg
+        l1_w, ssim_w, sigma, kind, planes, h, w, win, val_range, track, track2 = ctx.cfg
         g = gout.detach().to(torch.float32).reshape(1).contiguous()
-        da = torch.empty_like(a)
-        if kind == 0:
-            L.call("mrisr_ssim_l1_backward", a.data_ptr(), b.data_ptr(), L.ptr(coef), sums.data_ptr(), g.data_ptr(),
-                   l1_w, ssim_w, da.data_ptr(), planes, h, w, sigma, L.stream_ptr(),
-                   nbytes=planes * h * w * (12 + (12 if coef is not None else 0)))
-        else:   # d(mean ssim): weights (0, -1), no clamp
-            L.call("mrisr_ssim_l1_backward", a.data_ptr(), b.data_ptr(), L.ptr(coef), None, g.data_ptr(),
-                   0.0, -1.0, da.data_ptr(), planes, h, w, sigma, L.stream_ptr())
-        return da, None, None, None, None, None, None, None, None
+        st = L.stream_ptr()
+
+        def grad_first(x, y, cf):
+            dx = torch.empty_like(x)
+            if kind == 0:
+                L.call("mrisr_ssim_l1_backward_win", x.data_ptr(), y.data_ptr(), L.ptr(cf), sums.data_ptr(), g.data_ptr(),
+                       l1_w, ssim_w, dx.data_ptr(), planes, h, w, sigma, win, st,
+                       nbytes=planes * h * w * (12 + (12 if cf is not None else 0)))
+            else:   # d(mean ssim): weights (0, -1), no clamp
+                L.call("mrisr_ssim_l1_backward_win", x.data_ptr(), y.data_ptr(), L.ptr(cf), None, g.data_ptr(),
+                       0.0, -1.0, dx.data_ptr(), planes, h, w, sigma, win, st)
+            return dx
+
+        da = grad_first(a, b, coef) if track else None
+        db = None
+        if track2:
+            # SSIM and L1 are symmetric in their arguments (losses.py:55-73): the gradient w.r.t. the second image is the
+            # gradient w.r.t. the first one of the swapped pair, with the swapped pair's coefficient planes
+            coef2 = None
+            if ssim_w != 0:
+                coef2 = torch.empty(3 * planes * h * w, dtype=torch.float32, device=a.device)
+                scratch = torch.zeros(planes * 2, dtype=torch.float64, device=a.device)
+                L.call("mrisr_ssim_l1_forward_win", b.data_ptr(), a.data_ptr(), scratch.data_ptr(), coef2.data_ptr(), planes, h, w,
+                       val_range, sigma, win, st)
+            db = grad_first(b, a, coef2)
+        return da, db, None, None, None, None, None, None, None, None, None
 
 
 def ssim(img1, img2, window_size=11, sigma=1.5, val_range=1.0, device=None, window=None, size_average=True):
     """SSIM between img1 and img2, computed in fp32 with zero padding (reference losses.py:27-81).
     ``device`` / ``window`` are accepted for signature compatibility; the window is rebuilt from
     (window_size, sigma) inside the kernel."""
-    if window_size != _WINDOW:
-        raise NotImplementedError(f"the fused SSIM kernel supports window_size={_WINDOW} only")
-    if img2.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("gradient w.r.t. the second ssim() argument is not implemented")
+    _check_window(window_size)
     holder = type("H", (), {})()
-    val = _SSIML1.apply(img1, img2, 0.0, 1.0, sigma, val_range, 1, holder, torch.is_grad_enabled() and img1.requires_grad)
+    grads = torch.is_grad_enabled()
+    val = _SSIML1.apply(img1, img2, 0.0, 1.0, sigma, val_range, 1, holder, grads and img1.requires_grad, window_size,
+                        grads and img2.requires_grad)
     if size_average:
         result = val
     else:
@@ -202,8 +225,7 @@ class CombinedLoss(nn.Module):
             raise ValueError("perceptual_weight must be between 0 and 1")
         if ssim_weight + perceptual_weight > 1:
             raise ValueError("Sum of ssim_weight and perceptual_weight cannot exceed 1")
-        if window_size != _WINDOW:
-            raise NotImplementedError(f"the fused SSIM kernel supports window_size={_WINDOW} only")
+        _check_window(window_size)
         self.ssim_weight = ssim_weight
         self.perceptual_weight = perceptual_weight
         self.l1_weight = 1.0 - ssim_weight - perceptual_weight
@@ -225,8 +247,9 @@ class CombinedLoss(nn.Module):
             return 0.0                         # the reference returns the python float 0.0 here
         total = None
         if l1_w != 0.0 or s_w != 0.0:
+            grads = torch.is_grad_enabled()
             total = _SSIML1.apply(output, target, l1_w, s_w, self.sigma, self.val_range, 0, self,
-                                  torch.is_grad_enabled() and output.requires_grad)
+                                  grads and output.requires_grad, self.window_size, grads and target.requires_grad)
         if self.use_perceptual:                # losses.py:229-236
             perc = self.perceptual_loss(output, target)
             self.last_perceptual = perc.detach()
@@ -239,8 +262,7 @@ class SSIM(nn.Module):
 
     def __init__(self, window_size=11, sigma=1.5, val_range=1.0, device=None):
         super().__init__()
-        if window_size != _WINDOW:
-            raise NotImplementedError(f"the fused SSIM kernel supports window_size={_WINDOW} only")
+        _check_window(window_size)
         self.window_size = window_size
         self.sigma = sigma
         self.val_range = val_range

@@ -133,7 +133,34 @@ def case_train3(f=16, n=2, h=32, w=32, seed=3, ssim_weight=0.4, tag="train3"):
     print(tag, "losses", losses)
 
 
+def case_ssim_windows():
+    """ssim() / CombinedLoss with window sizes other than 11 and gradients to BOTH arguments (losses.py:27-81, 200-226)."""
+    g = torch.Generator().manual_seed(4242)
+    a = torch.rand(2, 1, 37, 53, generator=g)
+    b = (a + 0.2 * torch.rand(2, 1, 37, 53, generator=g) - 0.1).clamp(0, 1)
+    rec = {"a": a.numpy(), "b": b.numpy()}
+    for ws in (3, 7, 11, 15):
+        x, y = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        v = ssim(x, y, window_size=ws, sigma=1.5)
+        v.backward()
+        rec[f"ssim_w{ws}"] = np.float64(v.item())
+        rec[f"ssim_ps_w{ws}"] = ssim(a, b, window_size=ws, sigma=1.5, size_average=False).numpy()
+        rec[f"ga_w{ws}"], rec[f"gb_w{ws}"] = x.grad.numpy(), y.grad.numpy()
+        x, y = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        loss = CombinedLoss(ssim_weight=0.4, window_size=ws, device=torch.device("cpu"))(x, y)
+        loss.backward()
+        rec[f"closs_w{ws}"] = np.float64(loss.item())
+        rec[f"cga_w{ws}"], rec[f"cgb_w{ws}"] = x.grad.numpy(), y.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "ssim_windows.npz"), **rec)
+    print("ssim_windows", [float(rec[f"ssim_w{ws}"]) for ws in (3, 7, 11, 15)])
+
+
 def main():
+    if "--only-ssim-windows" in sys.argv:       # (added in round 3: leaves the earlier fixtures byte-identical)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        case_ssim_windows()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -142,6 +169,7 @@ def main():
     case_forward_backward("unet_f16_n1_50x70_odd", 16, 1, 50, 70, seed=4, ssim_ws=(0.4,))
     case_forward_backward("unet_f32_n1_64x64", 32, 1, 64, 64, seed=5, ssim_ws=(0.4,))
     case_ssim()
+    case_ssim_windows()
     case_train3()
     case_train3(ssim_weight=0.0, tag="train3_l1")
 

@@ -149,6 +149,36 @@ def test_ssim_and_combined_loss_match_reference_golden(golden_dir):
         assert (x2.grad.cpu() - xr.grad).abs().max().item() <= 2e-4 * xr.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("window_size", [3, 7, 11, 15])
+def test_ssim_window_sizes_and_gradient_to_both_images(golden_dir, window_size):
+    """`ssim(img1, img2, window_size, ...)` (losses.py:27-81) for odd windows 3..15 and the gradient w.r.t. BOTH arguments
+    (the reference's autograd gives both; its own callers only ever differentiate the first), and CombinedLoss with a
+    non-default window and a target that requires grad - against the REFERENCE's own values and gradients
+    (tests/golden/ssim_windows.npz).  Even windows are refused (the reference's maps grow by a pixel there)."""
+    g = _golden(golden_dir, "ssim_windows")
+    ws = window_size
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    x, y = a.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+    v = ssim(x, y, window_size=ws, sigma=1.5)
+    v.backward()
+    assert abs(v.item() - float(g[f"ssim_w{ws}"])) <= 1e-5
+    for got, key in ((x.grad, "ga"), (y.grad, "gb")):
+        ref = g[f"{key}_w{ws}"]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    ps = ssim(x.detach(), y.detach(), window_size=ws, size_average=False).cpu().numpy()
+    assert np.abs(ps - g[f"ssim_ps_w{ws}"]).max() <= 5e-6
+    assert abs(SSIM(window_size=ws)(x.detach(), y.detach()).item() - float(g[f"ssim_w{ws}"])) <= 1e-5
+    x2, y2 = a.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+    loss = CombinedLoss(ssim_weight=0.4, window_size=ws, device=torch.device("cuda"))(x2, y2)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"closs_w{ws}"])) <= 1e-5
+    for got, key in ((x2.grad, "cga"), (y2.grad, "cgb")):
+        ref = g[f"{key}_w{ws}"]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    with pytest.raises(NotImplementedError):
+        ssim(x.detach(), y.detach(), window_size=ws + 1)
+
+
 def test_ssim_metric_after_loss_reuses_the_pass_and_stays_exact():
     """train.py evaluates the SSIM metric on the tensors the loss has just seen: the second call is served from the
     loss's per-plane sums - only while both operands are unchanged (address, autograd version, no graph replay)."""

@@ -80,6 +80,29 @@ def test_ssim_matches_reference(golden_dir):
         assert np.abs(x.grad.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("ws", [3, 7, 11, 15])
+def test_ssim_window_sizes_and_both_gradients_match_reference(golden_dir, ws):
+    """The oracle against the reference run with other window sizes, gradients to BOTH images (tests/golden/ssim_windows.npz,
+    written by oracle/gen_golden.py --only-ssim-windows from the reference's own ssim / CombinedLoss)."""
+    g = _load(golden_dir, "ssim_windows")
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    x, y = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    v = ssim(x, y, ws, 1.5)
+    v.backward()
+    assert abs(float(v) - float(g[f"ssim_w{ws}"])) <= 1e-6
+    assert np.abs(ssim(a, b, ws, 1.5, size_average=False).numpy() - g[f"ssim_ps_w{ws}"]).max() <= 1e-6
+    for got, key in ((x.grad, "ga"), (y.grad, "gb")):
+        ref = g[f"{key}_w{ws}"]
+        assert np.abs(got.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    x, y = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    loss = combined_loss(x, y, 0.4, window_size=ws)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"closs_w{ws}"])) <= 1e-6
+    for got, key in ((x.grad, "cga"), (y.grad, "cgb")):
+        ref = g[f"{key}_w{ws}"]
+        assert np.abs(got.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("name", ["train3", "train3_l1"])
 def test_train3_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
