@@ -859,6 +859,95 @@ __device__ __forceinline__ float ld_coherent(const float* p) {      // red[] is 
     return __hip_atomic_load((const GLOBAL_AS float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The part every one-pass kernel shares.  In: this thread's sums of g (sA) and g*x (sB) over its pixels, channels c .. c+VEC-1 of
+// image n.  Block reduction -> atomics into this block's copy of red[] -> image barrier -> coefficients of dx = g cA + x cB + cC
+// for the thread's channels (act_bwd_finalize_kernel's formulas), dgamma / dbeta added once per image.  Every thread of the block
+// calls it.  lds: 256 * VEC * 2 + 2 * kMaxGroups floats.
+template <int VEC>
+__device__ __forceinline__ void onepass_meet(const ActBwdParams& p, const FinDev& fin, unsigned* __restrict__ arrive, float* lds,
+                                             int* timed_out, int n, int c, int nvec, int ppb, int pl, float* sA, float* sB,
+                                             float* ca, float* cb, float* cc) {
+    const int t = threadIdx.x, gs = p.C / p.groups;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {      // sum g*xhat = rstd * (sum g*x - mean * sum g), per thread (8 pixels)
+        const int g = (c + e) / gs;
+        const float mean = p.meanrstd[((size_t)n * p.groups + g) * 2], rstd = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
+        sB[e] = rstd * (sB[e] - mean * sA[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        lds[(t * VEC + e) * 2] = sA[e];
+        lds[(t * VEC + e) * 2 + 1] = sB[e];
+    }
+    if (t == 0) *timed_out = 0;
+    __syncthreads();
+    for (int i = t; i < nvec * VEC * 2; i += 256) {
+        const int j = i >> 1, which = i & 1;
+        const int cvj = j / VEC, e = j - cvj * VEC;
+        float s = 0.f;
+        for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
+        atomic_add_f32(&p.red[(((size_t)(blockIdx.x % kOnePassSlots) * p.N + n) * p.C + cvj * VEC + e) * 2 + which], s);
+    }
+    // ---- image barrier.  Everything that crosses it goes through agent-scope RELAXED atomics (the sums above, the counter,
+    // the reads of red[] below), which are performed at the memory side: no release / acquire fences - on this multi-XCD part
+    // each of them writes back or invalidates a whole L2, and with 4096 blocks doing so the launch ran 8x slower than the
+    // two launches it replaces.  `s_waitcnt vmcnt(0)`: this thread's atomics have been acknowledged before it is counted.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        // Two-level count, then a release flag per group of blocks: 256 blocks bumping and then polling ONE word is a chain of
+        // 256 same-address atomics at the memory side (~40 us per image, measured).  Block b belongs to group b % 16: it bumps
+        // its group's counter; the block that completes a group bumps the image's counter; the block that completes the image
+        // sets the 16 group flags; everybody polls its own group's flag (16 pollers per word, one cache line per word).
+        unsigned* img = arrive + (size_t)n * kOnePassWords;
+        const unsigned nblk = gridDim.x, g = blockIdx.x % kOnePassGroups;
+        const unsigned ngroups = min(nblk, (unsigned)kOnePassGroups), members = (nblk - g + kOnePassGroups - 1) / kOnePassGroups;
+        if (__hip_atomic_fetch_add(img + g * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == members) {
+            if (__hip_atomic_fetch_add(img + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == ngroups) {
+                for (unsigned k = 0; k < ngroups; ++k)
+                    __hip_atomic_store(img + 272 + k * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int spin = 0;
+        while (__hip_atomic_load(img + 272 + g * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(16);      // ~0.5 us between polls
+            if (++spin > 600000) { *timed_out = 1; break; }
+        }
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    const bool bad = *timed_out != 0;
+
+    // ---- coefficients of image n (act_bwd_finalize_kernel's formulas; red read around the L1)
+    float* s12 = lds;
+    if (t < 2 * kMaxGroups) s12[t] = 0.f;
+    __syncthreads();
+    const float* rn = fin.red + (size_t)n * p.C * 2;
+    const size_t slot_stride = (size_t)p.N * p.C * 2;
+    float* sums = lds + 2 * kMaxGroups;            // [C][2]: the image's per-channel sums, all slots added up
+    for (int j = t; j < 2 * p.C; j += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < kOnePassSlots; ++sl) v += ld_coherent(rn + sl * slot_stride + j);
+        sums[j] = v;
+        atomicAdd(&s12[(j & 1) * kMaxGroups + (j >> 1) / gs], fin.gamma[j >> 1] * v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (c + e) / gs;
+        const float mean = fin.meanrstd[((size_t)n * fin.groups + g) * 2], rstd = fin.meanrstd[((size_t)n * fin.groups + g) * 2 + 1];
+        const float S1 = s12[g] * fin.inv_count, S2 = s12[kMaxGroups + g] * fin.inv_count;
+        ca[e] = rstd * fin.gamma[c + e];
+        cb[e] = -rstd * rstd * S2;
+        cc[e] = bad ? __builtin_nanf("") : mean * rstd * rstd * S2 - rstd * S1;
+        if (blockIdx.x == 0 && pl == 0) {          // one block per image adds the image's share of dgamma / dbeta
+            atomic_add_f32(&fin.dbeta[c + e], sums[2 * (c + e)]);
+            atomic_add_f32(&fin.dgamma[c + e], sums[2 * (c + e) + 1]);
+        }
+    }
+}
+
 template <typename T, int NCONS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void act_bwd_onepass_kernel(const ActBwdParams p, T* __restrict__ dx, const FinDev fin,
                                                               unsigned* __restrict__ arrive) {
@@ -906,85 +995,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {      // sum g*xhat = rstd * (sum g*x - mean * sum g), per thread (8 pixels)
-        const int g = (c + e) / gs;
-        const float mean = p.meanrstd[((size_t)n * p.groups + g) * 2], rstd = p.meanrstd[((size_t)n * p.groups + g) * 2 + 1];
-        sB[e] = rstd * (sB[e] - mean * sA[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        lds[(t * VEC + e) * 2] = sA[e];
-        lds[(t * VEC + e) * 2 + 1] = sB[e];
-    }
-    if (t == 0) timed_out = 0;
-    __syncthreads();
-    for (int i = t; i < nvec * VEC * 2; i += 256) {
-        const int j = i >> 1, which = i & 1;
-        const int cvj = j / VEC, e = j - cvj * VEC;
-        float s = 0.f;
-        for (int q = 0; q < ppb; ++q) s += lds[((q * nvec + cvj) * VEC + e) * 2 + which];
-        atomic_add_f32(&p.red[(((size_t)(blockIdx.x % kOnePassSlots) * p.N + n) * p.C + cvj * VEC + e) * 2 + which], s);
-    }
-    // ---- image barrier.  Everything that crosses it goes through agent-scope RELAXED atomics (the sums above, the counter,
-    // the reads of red[] below), which are performed at the memory side: no release / acquire fences - on this multi-XCD part
-    // each of them writes back or invalidates a whole L2, and with 4096 blocks doing so the launch ran 8x slower than the
-    // two launches it replaces.  `s_waitcnt vmcnt(0)`: this thread's atomics have been acknowledged before it is counted.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-        // Two-level count, then a release flag per group of blocks: 256 blocks bumping and then polling ONE word is a chain of
-        // 256 same-address atomics at the memory side (~40 us per image, measured).  Block b belongs to group b % 16: it bumps
-        // its group's counter; the block that completes a group bumps the image's counter; the block that completes the image
-        // sets the 16 group flags; everybody polls its own group's flag (16 pollers per word, one cache line per word).
-        unsigned* img = arrive + (size_t)n * kOnePassWords;
-        const unsigned nblk = gridDim.x, g = blockIdx.x % kOnePassGroups;
-        const unsigned ngroups = min(nblk, (unsigned)kOnePassGroups), members = (nblk - g + kOnePassGroups - 1) / kOnePassGroups;
-        if (__hip_atomic_fetch_add(img + g * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == members) {
-            if (__hip_atomic_fetch_add(img + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == ngroups) {
-                for (unsigned k = 0; k < ngroups; ++k)
-                    __hip_atomic_store(img + 272 + k * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        int spin = 0;
-        while (__hip_atomic_load(img + 272 + g * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(16);      // ~0.5 us between polls
-            if (++spin > 600000) { timed_out = 1; break; }
-        }
-    }
-    asm volatile("" ::: "memory");
-    __syncthreads();
-    const bool bad = timed_out != 0;
-
-    // ---- phase 2: coefficients of image n (act_bwd_finalize_kernel's formulas; red read around the L1)
-    float* s12 = lds;
-    if (t < 2 * kMaxGroups) s12[t] = 0.f;
-    __syncthreads();
-    const float* rn = fin.red + (size_t)n * p.C * 2;
-    const size_t slot_stride = (size_t)p.N * p.C * 2;
-    float* sums = lds + 2 * kMaxGroups;            // [C][2]: the image's per-channel sums, all slots added up
-    for (int j = t; j < 2 * p.C; j += 256) {
-        float v = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < kOnePassSlots; ++sl) v += ld_coherent(rn + sl * slot_stride + j);
-        sums[j] = v;
-        atomicAdd(&s12[(j & 1) * kMaxGroups + (j >> 1) / gs], fin.gamma[j >> 1] * v);
-    }
-    __syncthreads();
     float ca[VEC], cb[VEC], cc[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const int g = (c + e) / gs;
-        const float mean = fin.meanrstd[((size_t)n * fin.groups + g) * 2], rstd = fin.meanrstd[((size_t)n * fin.groups + g) * 2 + 1];
-        const float S1 = s12[g] * fin.inv_count, S2 = s12[kMaxGroups + g] * fin.inv_count;
-        ca[e] = rstd * fin.gamma[c + e];
-        cb[e] = -rstd * rstd * S2;
-        cc[e] = bad ? __builtin_nanf("") : mean * rstd * rstd * S2 - rstd * S1;
-        if (blockIdx.x == 0 && pl == 0) {          // one block per image adds the image's share of dgamma / dbeta
-            atomic_add_f32(&fin.dbeta[c + e], sums[2 * (c + e)]);
-            atomic_add_f32(&fin.dgamma[c + e], sums[2 * (c + e) + 1]);
-        }
-    }
+    onepass_meet<VEC>(p, fin, arrive, lds, &timed_out, n, c, nvec, ppb, pl, sA, sB, ca, cb, cc);
     T* ob = dx + (size_t)n * HW * p.C + c;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -1004,8 +1016,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     }
 }
 
+// The same for a node whose activation is ALSO max-pooled (the encoder skips: one 2x2-pool consumer + at most one plain
+// consumer of the node's geometry; even H, W).  Thread = (pooled pixel, channel vector) owning whole 2x2 windows as in
+// act_bwd_pool_window_kernel: two windows per thread = 8 pixels' x, their plain-consumer gradients and two pooled gradients
+// in registers across the barrier; the arg-max is recomputed in phase 2 (a few vector instructions per element).
+constexpr int kOnePassWPT = 2;       // windows per thread
+template <typename T, bool HAS_O>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void act_bwd_onepass_window_kernel(const ActBwdParams p, T* __restrict__ dx,
+                                                                                                                  const FinDev fin, unsigned* __restrict__ arrive) {
+    constexpr int VEC = Vec16<T>::N, WPT = kOnePassWPT;
+    __shared__ float lds[256 * VEC * 2 + 2 * kMaxGroups];
+    __shared__ int timed_out;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int nvec = p.C / VEC, ppb = 256 / nvec;
+    const int cv = t & (nvec - 1), pl = t / nvec, c = cv * VEC;
+    const int W = p.W, Hp = p.H / 2, Wp = W / 2, HWp = Hp * Wp;
+    const int kp = p.cons[0].spatial == MRISR_SP_POOL2 ? 0 : 1, ko = 1 - kp;
+    const int w0 = blockIdx.x * (ppb * WPT) + pl;
+    float sc[VEC], sh[VEC];
+    const size_t k0 = (size_t)n * p.C + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sc[e] = p.scale[k0 + e]; sh[e] = p.shift[k0 + e]; }
+    const T* xb = (const T*)p.x + (size_t)n * p.H * W * p.C + c;
+    const T* dpb = (const T*)p.cons[kp].da + (size_t)n * HWp * p.cons[kp].C_total + p.cons[kp].c_off + c;
+    const int Cto = HAS_O ? p.cons[ko].C_total : 0;
+    const T* dob = HAS_O ? (const T*)p.cons[ko].da + (size_t)n * p.H * W * Cto + p.cons[ko].c_off + c : xb;
+
+    Vec16<T> xv[WPT][4], dv[HAS_O ? WPT : 1][4], dp[WPT];
+    unsigned off[WPT];                  // pixel index of the window's top-left corner
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int pp = min(w0 + i * ppb, HWp - 1);              // (the tail block re-reads the last window; masked below)
+        const int py = pp / Wp, px = pp - py * Wp;
+        off[i] = (unsigned)(2 * py) * W + 2 * px;
+        const unsigned o4[4] = {off[i], off[i] + 1, off[i] + (unsigned)W, off[i] + (unsigned)W + 1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[i][q] = load_vec16(xb + (size_t)o4[q] * p.C);
+        dp[i] = load_vec16(dpb + (size_t)pp * p.cons[kp].C_total);
+        if (HAS_O) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dv[i][q] = load_vec16(dob + (size_t)o4[q] * Cto);
+        }
+    }
+    // gradient w.r.t. the GroupNorm output at the four pixels of window i, channel e (act_bwd_pool_window_kernel's arithmetic:
+    // first maximum of the activations in scan order takes the pooled gradient)
+    auto window_g = [&](int i, int e, float* xr, float* gy) {
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xr[q] = xv[i][q].get(e); pre[q] = xr[q] * sc[e] + sh[e]; }
+        int win = 0;
+        float m = lrelu(pre[0]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float a = lrelu(pre[q]);
+            if (a > m) { m = a; win = q; }
+        }
+        const float gp = dp[i].get(e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gact = q == win ? gp : 0.f;
+            if (HAS_O) gact += dv[i][q].get(e);
+            gy[q] = gact * (pre[q] > 0.f ? 1.f : LRELU_SLOPE);
+        }
+    };
+    float sA[VEC], sB[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sA[e] = 0.f; sB[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        if (w0 + i * ppb < HWp) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float xr[4], gy[4];
+                window_g(i, e, xr, gy);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sA[e] += gy[q]; sB[e] += gy[q] * xr[q]; }
+            }
+        }
+    }
+    float ca[VEC], cb[VEC], cc[VEC];
+    onepass_meet<VEC>(p, fin, arrive, lds, &timed_out, n, c, nvec, ppb, pl, sA, sB, ca, cb, cc);
+    T* ob = dx + (size_t)n * p.H * W * p.C + c;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        if (w0 + i * ppb < HWp) {
+            Vec16<T> ov[4];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float xr[4], gy[4];
+                window_g(i, e, xr, gy);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ov[q].set(e, gy[q] * ca[e] + xr[q] * cb[e] + cc[e]);
+            }
+            const unsigned o4[4] = {off[i], off[i] + 1, off[i] + (unsigned)W, off[i] + (unsigned)W + 1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store_vec16(ob + (size_t)o4[q] * p.C, ov[q]);
+        }
+    }
+}
+
 // Does a node qualify for the one-pass kernel?  (16-bit storage, plain consumers of the node's own geometry without blend
 // weights, C / 8 a power of two <= 256, at most kOnePassMaxBlocks blocks per image)
+// 0 = no, 1 = plain consumers (act_bwd_onepass_kernel), 2 = one 2x2-pool consumer (+ at most one plain one): window kernel
 extern "C" int mrisr_act_bwd_onepass_ok(int dtype, int nconsumers, const mrisr_consumer* consumers, int N, int H, int W, int C) {
     if (dtype != MRISR_BF16 && dtype != MRISR_F16) return 0;
     if (!consumers || nconsumers < 1 || nconsumers > 2 || N < 1) return 0;
@@ -1013,14 +1125,23 @@ extern "C" int mrisr_act_bwd_onepass_ok(int dtype, int nconsumers, const mrisr_c
     if (C % vec) return 0;
     const int nvec = C / vec;
     if (nvec > 256 || (nvec & (nvec - 1))) return 0;
-    for (int k = 0; k < nconsumers; ++k) {
-        const mrisr_consumer& c = consumers[k];
-        if (c.spatial != MRISR_SP_NONE || c.H != H || c.W != W || c.off_y || c.off_x || c.weight_mode) return 0;
-    }
     const long HW = (long)H * W;
     if (HW * C >= (1l << 30)) return 0;
-    const int ppblk = (256 / nvec) * kOnePassPPT;
-    return (HW + ppblk - 1) / ppblk <= kOnePassMaxBlocks ? 1 : 0;
+    bool plain = true;
+    for (int k = 0; k < nconsumers; ++k) {
+        const mrisr_consumer& c = consumers[k];
+        if (c.weight_mode) return 0;
+        if (c.spatial != MRISR_SP_NONE || c.H != H || c.W != W || c.off_y || c.off_x) plain = false;
+    }
+    if (plain) {
+        const int ppblk = (256 / nvec) * kOnePassPPT;
+        return (HW + ppblk - 1) / ppblk <= kOnePassMaxBlocks ? 1 : 0;
+    }
+    if (!act_bwd_window_ok(nconsumers, consumers, H, W)) return 0;
+    for (int k = 0; k < nconsumers; ++k)
+        if (consumers[k].spatial == MRISR_SP_POOL2 && (consumers[k].H != H / 2 || consumers[k].W != W / 2)) return 0;
+    const int wpblk = (256 / nvec) * kOnePassWPT;
+    return (HW / 4 + wpblk - 1) / wpblk <= kOnePassMaxBlocks ? 2 : 0;
 }
 
 // red: [kOnePassSlots = 16][N][C][2] floats and arrive: [N][kOnePassWords = 544] barrier words, both ZERO on entry (the engine's per-backward arena).
@@ -1045,9 +1166,23 @@ extern "C" int mrisr_act_bwd_onepass(int dtype, const void* x, const float* scal
     p.ncons = nconsumers; p.N = N; p.H = H; p.W = W; p.C = C; p.groups = fin->groups;
     int rc = fill_act_bwd_params(p, dtype, nconsumers, consumers, nullptr, H, W, C, "act_bwd_onepass");
     if (rc) return rc;
-    const int nvec = C / mrisr_vec(dtype), ppblk = (256 / nvec) * kOnePassPPT;
-    dim3 grid(ceil_div(H * W, ppblk), N);
+    const int kind = mrisr_act_bwd_onepass_ok(dtype, nconsumers, consumers, N, H, W, C);
+    const int nvec = C / mrisr_vec(dtype);
     hipStream_t s = (hipStream_t)stream;
+    if (kind == 2) {
+        const bool has_o = nconsumers > 1;
+        dim3 grid(ceil_div(H * W / 4, (256 / nvec) * kOnePassWPT), N);
+        if (dtype == MRISR_BF16) {
+            if (has_o) act_bwd_onepass_window_kernel<bf16_t, true><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, fd, arrive);
+            else act_bwd_onepass_window_kernel<bf16_t, false><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, fd, arrive);
+        } else {
+            if (has_o) act_bwd_onepass_window_kernel<f16_t, true><<<grid, 256, 0, s>>>(p, (f16_t*)dx, fd, arrive);
+            else act_bwd_onepass_window_kernel<f16_t, false><<<grid, 256, 0, s>>>(p, (f16_t*)dx, fd, arrive);
+        }
+        MRISR_CHECK_LAUNCH("act_bwd_onepass(window)");
+        return MRISR_OK;
+    }
+    dim3 grid(ceil_div(H * W, (256 / nvec) * kOnePassPPT), N);
     if (dtype == MRISR_BF16) {
         if (nconsumers == 1) act_bwd_onepass_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, fd, arrive);
         else act_bwd_onepass_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p, (bf16_t*)dx, fd, arrive);

@@ -497,11 +497,12 @@ class UNetEngine:
             # (one image's blocks - at most 256, i.e. ~86 CUs' worth of waves - must be resident together; under data parallelism
             # the RCCL kernels of the overlapped all-reduce hold CUs as well, so only nodes of <= 128 blocks per image take it)
             op_blocks = -(-(n.H * n.W) // ((256 // max(n.C // 8, 1)) * 8)) if n.C >= 8 else 1 << 30
-            if (fused and plain and slots is None and not uses_alpha and not TUNING.no_onepass
+            if (fused and slots is None and not uses_alpha and not TUNING.no_onepass
                     and op_blocks <= (128 if bucket_hook is not None else 256)
                     and L.load().mrisr_act_bwd_onepass_ok(dt, len(n.consumers), cons, N, n.H, n.W, n.C)):
-                # plain consumers of the node's own geometry: ONE launch that reads x and the consumer gradients once and
-                # keeps them in registers across an in-kernel image barrier (csrc/norm.hip: act_bwd_onepass_kernel)
+                # plain consumers of the node's own geometry (or a 2x2-pooled node on even dims): ONE launch that reads x and the
+                # consumer gradients once and keeps them in registers across an in-kernel image barrier (csrc/norm.hip:
+                # act_bwd_onepass_kernel / act_bwd_onepass_window_kernel)
                 arrive = red[SL * N * n.C * 2 + 256:SL * N * n.C * 2 + 256 + narr]
                 fin = L.GnBwdFin(red.data_ptr(), params[n.gamma].data_ptr(), n.meanrstd.data_ptr(),
                                  grads[n.gamma].data_ptr(), grads[n.beta].data_ptr(), None, None, None,

@@ -496,37 +496,47 @@ def test_act_backward(dt, mode):
 
 
 @pytest.mark.parametrize("dt", [L.BF16, L.F16])
-@pytest.mark.parametrize("case", ["one_block", "many_blocks", "two_consumers", "tail_block", "wide"])
+@pytest.mark.parametrize("case", ["one_block", "many_blocks", "two_consumers", "tail_block", "wide", "pool", "pool+skip", "pool_tail"])
 def test_act_backward_onepass(dt, case):
     """mrisr_act_bwd_onepass (csrc/norm.hip: act_bwd_onepass_kernel, in-kernel image barrier): GroupNorm + LeakyReLU backward
     of a node with plain consumers of its own geometry in ONE launch, against autograd of F.group_norm + F.leaky_relu
     (unet_model.py:30-31) and against the two-pass kernels on the same operands.  many_blocks: 64 blocks per image, 6 images
     (the barrier is crossed by many blocks on different XCDs); two_consumers: skip concat window (c_off) + a second plain
-    consumer; tail_block: the pixel count is not a multiple of the block's; wide: 64 channel vectors per pixel."""
+    consumer; tail_block: the pixel count is not a multiple of the block's; wide: 64 channel vectors per pixel; pool /
+    pool+skip / pool_tail: the node is also 2x2 max-pooled (encoder skips x1..x3, unet_model.py:56, 192-194) - the window form,
+    with and without the skip-concat consumer, and with a window count that is not a multiple of the block's."""
     n, c, h, w, two = {"one_block": (2, 32, 8, 32, False), "many_blocks": (6, 64, 128, 128, False),
                        "two_consumers": (3, 64, 48, 64, True), "tail_block": (2, 32, 19, 27, False),
-                       "wide": (2, 512, 16, 16, True)}[case]
+                       "wide": (2, 512, 16, 16, True), "pool": (3, 64, 64, 96, False), "pool+skip": (4, 128, 64, 64, True),
+                       "pool_tail": (2, 32, 18, 26, True)}[case]
+    pooled = case.startswith("pool")
     x = rnd(n, c, h, w, seed=140)
     gamma, beta = 1 + 0.2 * rnd(c, seed=141), 0.1 * rnd(c, seed=142)
     scale, shift, mr = _gn_forward_state(x, gamma, beta, dt)
     xr = U.rounded(x, dt).requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     act = F.leaky_relu(F.group_norm(xr, 8, gr, br, 1e-5), 0.2)
-    da = rnd(n, c + 8, h, w, seed=143)
-    loss = (act * U.rounded(da, dt)[:, 8:]).sum()
-    cons = [(da, c + 8, 8)]
-    if two:
+    cons, loss = [], 0
+    if pooled:
+        dpl = rnd(n, c, h // 2, w // 2, seed=145)
+        loss = loss + (F.max_pool2d(act, 2) * U.rounded(dpl, dt)).sum()
+        cons.append((dpl, c, 0, h // 2, w // 2, L.SP_POOL2))
+    if not pooled or two:
+        da = rnd(n, c + 8, h, w, seed=143)
+        loss = loss + (act * U.rounded(da, dt)[:, 8:]).sum()
+        cons.append((da, c + 8, 8, h, w, L.SP_NONE))
+    if two and not pooled:
         db = rnd(n, c, h, w, seed=144)
         loss = loss + (act * U.rounded(db, dt)).sum()
-        cons.append((db, c, 0))
+        cons.append((db, c, 0, h, w, L.SP_NONE))
     loss.backward()
     carr, keep = (L.Consumer * 2)(), []
-    for i, (d, ctot, coff) in enumerate(cons):
+    for i, (d, ctot, coff, ch, cw, sp) in enumerate(cons):
         dd = U.nhwc(d, dt)
         keep.append(dd)
-        carr[i].da, carr[i].C_total, carr[i].c_off, carr[i].H, carr[i].W = dd.data_ptr(), ctot, coff, h, w
-        carr[i].spatial, carr[i].off_y, carr[i].off_x, carr[i].weight_mode = L.SP_NONE, 0, 0, 0
-    assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, h, w, c) == 1
+        carr[i].da, carr[i].C_total, carr[i].c_off, carr[i].H, carr[i].W = dd.data_ptr(), ctot, coff, ch, cw
+        carr[i].spatial, carr[i].off_y, carr[i].off_x, carr[i].weight_mode = sp, 0, 0, 0
+    assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, h, w, c) == (2 if pooled else 1)
     xd, gdev = U.nhwc(x, dt), gamma.to(U.DEV)
     count = float((c // 8) * h * w)
 
@@ -551,7 +561,7 @@ def test_act_backward_onepass(dt, case):
     dx1, dg1, db1, arrive = run(True)
     assert torch.isfinite(dx1).all(), "a block gave up waiting at the image barrier"
     nvec = c // 8
-    blocks = -(-(h * w) // ((256 // nvec) * 8))
+    blocks = -(-(h * w // 4) // ((256 // nvec) * 2)) if pooled else -(-(h * w) // ((256 // nvec) * 8))
     words = arrive.view(n, -1)
     assert (words[:, 0:256:16].sum(1) == blocks).all() and (words[:, 256] == min(blocks, 16)).all()     # everybody was counted
     tol = 2e-2
@@ -563,9 +573,14 @@ def test_act_backward_onepass(dt, case):
     assert U.relerr(dx1, dx2) <= 4e-3
     assert U.relerr(dg1, dg2) <= 1e-4 and U.relerr(db1, db2) <= 1e-4
     # nodes that do not qualify are refused, not mis-computed
-    carr[0].off_x = 1
+    k = len(cons) - 1
+    carr[k].weight_mode = 1                     # a blend branch
     assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, h, w, c) == 0
-    carr[0].off_x = 0
+    carr[k].weight_mode = 0
+    if carr[k].spatial == L.SP_NONE:
+        carr[k].off_x = 1                       # a padded consumer
+        assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, h, w, c) == 0
+        carr[k].off_x = 0
     assert L.load().mrisr_act_bwd_onepass_ok(dt, len(cons), carr, n, 512, 512, 32) == 0      # 512 blocks per image
 
 
