@@ -46,16 +46,21 @@ __device__ unsigned long long g_pc_cycles[8][12];
 
 typedef __attribute__((ext_vector_type(2))) float pc_f32x2;      // pairs for v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
 
-constexpr int kPcThreads = 512;
-constexpr int kPcBN = 128;                       // output channels per workgroup
+constexpr int kPcThreads = 512;                  // 4 MFMA waves + 4 staging waves
+// staging waves (a parameter of the layouts below; 8 for the blend variant was tried: 376 instead of 280 us - more staging
+// waves do not make its 32-channel items cheaper)
+constexpr int pc_np(bool blend) { return blend ? 4 : 4; }
+constexpr int pc_threads(bool blend) { return 256 + 64 * pc_np(blend); }
+constexpr int kPcBN = 128;                       // output channels per workgroup (NI = 4; the narrow variant NI = 1 owns 32)
 constexpr int kPcHaloW = 34, kPcHaloH = 10, kPcHaloRows = kPcHaloW * kPcHaloH;     // 8 x 32 pixel tile + halo
-constexpr int kPcHaloSlots = 3;                  // 16-byte vectors per staging thread: 256 x 3 >= 340 rows x 2
-constexpr int kPcHaloBytes = 256 * kPcHaloSlots * 16;        // (the last slot stores unpredicated: 768 vectors of room)
-constexpr int kPcWBytes = 9 * kPcBN * 32;        // weight image of one (cout block, cin chunk)
-constexpr int kPcWSlots = kPcWBytes / (256 * 16);
-constexpr int kPcBuf = kPcHaloBytes + kPcWBytes;
-constexpr int kPcStages = 3;                     // LDS item buffers (3 x 48 KiB)
-constexpr int kPcLds = kPcStages * kPcBuf + kPcBN * 4 + 64;      // + bias table + the two item counters
+// 16-byte vectors per staging thread: 340 halo rows x 2 over 64 np threads (the last slot stores unpredicated: whole slots of room)
+constexpr int pc_hslots(int np) { return (2 * kPcHaloRows + 64 * np - 1) / (64 * np); }
+constexpr int pc_hbytes(int np) { return pc_hslots(np) * 64 * np * 16; }
+constexpr int pc_wbytes(int ni) { return 9 * 32 * ni * 32; }                     // weight image of one (cout block, cin chunk)
+constexpr int pc_wslots(int ni, int np) { return (pc_wbytes(ni) / 16 + 64 * np - 1) / (64 * np); }
+constexpr int pc_buf(int ni, int np) { return pc_hbytes(np) + pc_wslots(ni, np) * 64 * np * 16; }
+constexpr int kPcStages = 3;                     // LDS item buffers (3 x 48 KiB at NI = 4)
+constexpr int pc_lds(int ni, int np) { return kPcStages * pc_buf(ni, np) + kPcBN * 4 + 64; }   // + bias table + the item counters
 
 // Item counters in LDS instead of workgroup barriers: the staging waves may run up to two items ahead of the MFMA waves
 // (they keep staging while a tile's epilogue runs) and nobody waits for the slowest wave of the OTHER role at every item.
@@ -71,28 +76,45 @@ __device__ __forceinline__ void pc_signal(unsigned lds_addr) {
 }
 // (the polls are volatile LDS loads, not asm: hipcc's own `s_waitcnt lgkmcnt` bookkeeping must see every LDS operation)
 __device__ __forceinline__ int pc_min4(const u32x4 v) { return min(min((int)v[0], (int)v[1]), min((int)v[2], (int)v[3])); }
-__device__ __forceinline__ u32x4 pc_peek(const unsigned* cnt4) {
-    return *reinterpret_cast<const volatile u32x4*>(cnt4);
+// NV vectors of four counters, element-wise minimum
+template <int NV>
+__device__ __forceinline__ u32x4 pc_peek(const unsigned* cnt) {
+    u32x4 m = *reinterpret_cast<const volatile u32x4*>(cnt);
+#pragma unroll
+    for (int i = 1; i < NV; ++i) {
+        const u32x4 v = *reinterpret_cast<const volatile u32x4*>(cnt + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = min(m[e], v[e]);
+    }
+    return m;
 }
 // `seen`: a peek taken earlier (the answer is usually already there: no LDS round trip on the critical path)
-__device__ __forceinline__ void pc_wait_ge(const unsigned* cnt4, u32x4 seen, int target, bool& broken) {
+template <int NV>
+__device__ __forceinline__ void pc_wait_ge(const unsigned* cnt, u32x4 seen, int target, bool& broken) {
     if (!broken && target > 0) {
         int spin = 0;
         while (__builtin_amdgcn_readfirstlane(pc_min4(seen)) < target) {
             if (++spin > (1 << 21)) { broken = true; break; }
             __builtin_amdgcn_s_sleep(2);
-            seen = pc_peek(cnt4);
+            seen = pc_peek<NV>(cnt);
         }
     }
     asm volatile("" ::: "memory");
 }
 
-template <typename T, bool NORM, bool STATS>
-__global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams p_in) {
+// NI = 32-channel fragments per MFMA wave (4: 128 output channels per workgroup; 1: the 32-channel layer of the 2x head);
+// BLEND: the input is sigmoid(alpha) * act(src0) + (1 - sigmoid(alpha)) * act(src1) (unet_model.py:206-207), formed by the
+// staging waves - the blended tensor never goes to HBM (eval forward of final_conv.0)
+template <typename T, bool NORM, bool STATS, int NI = 4, bool BLEND = false>
+__global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams p = pin_params(p_in);
     typedef typename Frag16<T>::type frag_t;
-    constexpr int MI = 2, NI = 4, BN = kPcBN, VEC = 8;
+    constexpr int MI = 2, BN = 32 * NI, VEC = 8;
+    constexpr int NP = pc_np(BLEND), PT = 64 * NP;                  // staging waves / threads
+    constexpr int kPcHaloSlots = pc_hslots(NP), kPcHaloBytes = pc_hbytes(NP);
+    constexpr int kPcWBytes = pc_wbytes(NI), kPcWSlots = pc_wslots(NI, NP), kPcBuf = pc_buf(NI, NP);
+    static_assert(!BLEND || NORM, "the blend is of two activated sources");
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool consumer = wave < 4;
@@ -114,6 +136,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     const int bn0 = cb * BN;
     if (total <= 0) return;
     if (t < BN) lds_bias[t] = p.bias ? gload<float>(p.bias + bn0 + t) : 0.f;
+    const float blend_a = BLEND ? 1.f / (1.f + __expf(-gload<float>(p.blend_alpha))) : 1.f;
     if (t < 16) lds_cnt[t] = 0u;
     __syncthreads();                    // the only workgroup barrier: bias table and counters are set up
 
@@ -125,6 +148,17 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         tx0 = tx * 32;
     };
 
+    // the next tile of the linear order without divisions (decode() costs ~100 vector instructions on uniform values; with two
+    // items per tile - the 32-channel layer - that was a third of the staging waves' time)
+    auto next_tile = [&](int& n, int& ty0, int& tx0) {
+        tx0 += 32;
+        if (tx0 == p.tiles_x * 32) {
+            tx0 = 0;
+            ty0 += 8;
+            if (ty0 == p.tiles_y * 8) { ty0 = 0; ++n; }
+        }
+    };
+
     // ------------------------------------------------------------------ schedule
     //   consumers:  wait ready(k) -> MFMA(item k) from buffer k % 3 -> signal done (+ the tile's epilogue behind its last item)
     //   producers:  wait done(k - 3) -> commit(item k) into buffer k % 3 -> signal ready -> issue loads(item k+2) into the
@@ -132,15 +166,17 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     // Two separate loops: neither role's registers are live in the other's code.
     if (!consumer) {
         // ------------------------------------------------------------------ producer (waves 4-7): 256 staging threads
-        const int pt = t & 255;
+        const int pt = t - 256;
         // halo vector v = pt + 256 j lies at LDS byte 16 v: row v >> 1 = (pt >> 1) + 128 j, physical slot pt & 1, which holds
         // the LOGICAL 8-channel half (pt & 1) ^ ((row >> 3) & 1) = (pt & 1) ^ ((pt >> 4) & 1)
         const int hrow0 = pt >> 1;
         const int lslot = (pt & 1) ^ ((pt >> 4) & 1);
         struct StageSet {
             Vec16<T> h[kPcHaloSlots];
+            Vec16<T> h2[BLEND ? kPcHaloSlots : 1];  // second source of the blend
             u32x4 w[kPcWSlots];
             pc_f32x2 sc[VEC / 2], sh[VEC / 2];     // GroupNorm affine of this thread's 8 channels, as pairs (packed fp32 math)
+            pc_f32x2 sc2[BLEND ? VEC / 2 : 1], sh2[BLEND ? VEC / 2 : 1];
             int ty0, tx0, w1;
         };
         StageSet S0, S1;
@@ -167,7 +203,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         unsigned fflags = 0;
 #pragma unroll
         for (int j = 0; j < kPcHaloSlots; ++j) {
-            const int row = hrow0 + 128 * j;
+            const int row = hrow0 + (PT / 2) * j;
             const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;        // row / 34 for row < 1000
             rel0[j] = (unsigned)((hy * p.src[0].W + hx) * p.src[0].C + lslot * VEC) * 2u;
             rel1[j] = two ? (unsigned)((hy * p.src[1].W + hx) * p.src[1].C + lslot * VEC) * 2u : rel0[j];
@@ -182,7 +218,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         // with scalar selects.  Halo offsets outside the tensor return zeros (hardware range check); halo pixels beside the
         // plane alias into neighbouring rows and are overwritten with zeros at commit time (edge tiles only).
         auto issue = [&](StageSet& S, int n, int ty0, int tx0, int kc) {
-            const bool w1 = two && kc * 16 >= C0;
+            const bool w1 = !BLEND && two && kc * 16 >= C0;
             const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W, Cs = w1 ? p.src[1].C : C0;
             const int offy = w1 ? p.src[1].off_y : p.src[0].off_y, offx = w1 ? p.src[1].off_x : p.src[0].off_x;
             const int cs = kc * 16 - (w1 ? C0 : 0);
@@ -192,11 +228,15 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
             for (int j = 0; j < kPcHaloSlots; ++j) {
                 const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tile_off + (w1 ? rel1[j] : rel0[j])), 0, 0);
                 S.h[j].v = __builtin_bit_cast(decltype(S.h[j].v), r);
+                if (BLEND) {        // (host-checked: the two sources have the same geometry)
+                    const u32x4 r2 = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc1, (int)(tile_off + rel0[j]), 0, 0);
+                    S.h2[j].v = __builtin_bit_cast(decltype(S.h2[j].v), r2);
+                }
             }
             const int woff = (cb * p.nchunks + kc) * kPcWBytes;
 #pragma unroll
             for (int j = 0; j < kPcWSlots; ++j)
-                S.w[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(wv + 4096u * j), woff, 0);
+                S.w[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(wv + 16u * PT * j), woff, 0);
 #ifdef PC_GLOBAL_AFF
             if (NORM) {
                 const float* scp = (w1 ? p.src[1].scale : p.src[0].scale) + (size_t)n * Cs + cs + lslot * VEC;
@@ -218,6 +258,12 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                     const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(shr, aff_v + e * 4, aoff, 0));
                     S.sc[e / 2] = pc_f32x2{a[0], a[1]}; S.sc[e / 2 + 1] = pc_f32x2{a[2], a[3]};
                     S.sh[e / 2] = pc_f32x2{b[0], b[1]}; S.sh[e / 2 + 1] = pc_f32x2{b[2], b[3]};
+                    if (BLEND) {
+                        const f32x4 a2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc1, aff_v + e * 4, aoff, 0));
+                        const f32x4 b2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sh_rsrc1, aff_v + e * 4, aoff, 0));
+                        S.sc2[e / 2] = pc_f32x2{a2[0], a2[1]}; S.sc2[e / 2 + 1] = pc_f32x2{a2[2], a2[3]};
+                        S.sh2[e / 2] = pc_f32x2{b2[0], b2[1]}; S.sh2[e / 2 + 1] = pc_f32x2{b2[2], b2[3]};
+                    }
                 }
             }
 #endif
@@ -234,29 +280,31 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
 #pragma unroll
             for (int j = 0; j < kPcHaloSlots; ++j) {
                 Vec16<T> v = S.h[j];
-                if (NORM && !(MRISR_PC_DBG & 2)) {
+                if (BLEND) {
+                    // sigmoid(alpha) * act(src0) + (1 - sigmoid(alpha)) * act(src1) in fp32, rounded once (as the classic blend
+                    // loader and norm_blend_kernel)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float y0 = fmaf(v.get(e), S.sc[e / 2][e & 1], S.sh[e / 2][e & 1]);
+                        const float y1 = fmaf(S.h2[j].get(e), S.sc2[e / 2][e & 1], S.sh2[e / 2][e & 1]);
+                        const float a0 = fmaxf(y0, LRELU_SLOPE * y0), a1 = fmaxf(y1, LRELU_SLOPE * y1);
+                        v.set(e, blend_a * a0 + (1.f - blend_a) * a1);
+                    }
+                } else if (NORM && !(MRISR_PC_DBG & 2)) {
 #pragma unroll
                     for (int e = 0; e < VEC; e += 2) {
                         // scalar fp32 math on purpose: v_pk_fma_f32 / v_pk_mul_f32 beside the other wave's MFMAs made this
                         // loop ~3x slower (down1.3 forward 82 -> 105 us, A/B)
                         const float ya = fmaf(v.get(e), S.sc[e / 2][0], S.sh[e / 2][0]), yb = fmaf(v.get(e + 1), S.sc[e / 2][1], S.sh[e / 2][1]);
-#ifdef PC_PK
-                        const pc_f32x2 x = {v.get(e), v.get(e + 1)};
-                        const pc_f32x2 y = __builtin_elementwise_fma(x, S.sc[e / 2], S.sh[e / 2]);
-                        const pc_f32x2 y2 = y * LRELU_SLOPE;
-                        v.set(e, fmaxf(y[0], y2[0]));
-                        v.set(e + 1, fmaxf(y[1], y2[1]));
-                        continue;
-#endif
                         v.set(e, fmaxf(ya, LRELU_SLOPE * ya));
                         v.set(e + 1, fmaxf(yb, LRELU_SLOPE * yb));
                     }
                 }
-                *reinterpret_cast<decltype(v.v)*>(lds_h + (q + 256 * j) * 16) = v.v;
+                *reinterpret_cast<decltype(v.v)*>(lds_h + (q + PT * j) * 16) = v.v;
             }
             PPT_MARK(0)
 #pragma unroll
-            for (int j = 0; j < kPcWSlots; ++j) *reinterpret_cast<u32x4*>(lds_w + (q + 256 * j) * 16) = S.w[j];
+            for (int j = 0; j < kPcWSlots; ++j) *reinterpret_cast<u32x4*>(lds_w + (q + PT * j) * 16) = S.w[j];
             PPT_MARK(1)
             issue(S, n, ty0, tx0, kc);
             PPT_MARK(3)
@@ -276,15 +324,15 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                     const unsigned hit = fflags & (tm * 0x111u);
 #pragma unroll
                     for (int j = 0; j < kPcHaloSlots; ++j)
-                        if (hit & (0xfu << (4 * j))) *reinterpret_cast<decltype(z.v)*>(lds_h + (q + 256 * j) * 16) = z.v;
+                        if (hit & (0xfu << (4 * j))) *reinterpret_cast<decltype(z.v)*>(lds_h + (q + PT * j) * 16) = z.v;
                 } else {
 #pragma unroll
                     for (int j = 0; j < kPcHaloSlots; ++j) {
-                        const int row = (q >> 1) + 128 * j;
+                        const int row = (q >> 1) + (PT / 2) * j;
                         const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;
                         const unsigned y = ys0 + hy, x = xs0 + hx;
                         if (row < kPcHaloRows && !(y < (unsigned)Hs && x < (unsigned)Ws))
-                            *reinterpret_cast<decltype(z.v)*>(lds_h + (q + 256 * j) * 16) = z.v;
+                            *reinterpret_cast<decltype(z.v)*>(lds_h + (q + PT * j) * 16) = z.v;
                     }
                 }
             }
@@ -300,7 +348,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                 if (++l_kc == p.nchunks) {
                     l_kc = 0;
                     ++l_tile;
-                    decode(l_tile, ln, lty0, ltx0);
+                    next_tile(ln, lty0, ltx0);
                 }
             }
         };
@@ -316,19 +364,19 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         u32x4 dseen = {0u, 0u, 0u, 0u};
 #pragma unroll 1
         for (int c = 0; c < total; c += 2) {
-            pc_wait_ge(done_p, dseen, c - 2, broken);         // item c - 3 (same buffer) has been read by all four MFMA waves
+            pc_wait_ge<1>(done_p, dseen, c - 2, broken);         // item c - 3 (same buffer) has been read by all four MFMA waves
             PPT_MARK(5)
             commit_issue(S0, smem + bi * kPcBuf, ln, lty0, ltx0, l_kc);
             if (lane == 0) pc_signal(ready_a + 4 * (wave - 4));
-            dseen = pc_peek(done_p);
+            dseen = pc_peek<1>(done_p);
             step();
             bi = bi == kPcStages - 1 ? 0 : bi + 1;
             PPT_MARK(6)
-            pc_wait_ge(done_p, dseen, c - 1, broken);
+            pc_wait_ge<1>(done_p, dseen, c - 1, broken);
             PPT_MARK(5)
             commit_issue(S1, smem + bi * kPcBuf, ln, lty0, ltx0, l_kc);
             if (lane == 0) pc_signal(ready_a + 4 * (wave - 4));
-            dseen = pc_peek(done_p);
+            dseen = pc_peek<1>(done_p);
             step();
             bi = bi == kPcStages - 1 ? 0 : bi + 1;
             PPT_MARK(6)
@@ -360,7 +408,9 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     const int gs = p.groups > 0 ? p.Cout / p.groups : 4;
     // GroupNorm partial sums per lane: a group spans >= 16 channels here (host-checked), i.e. the quad pairs {0,1} and {2,3}
     // of a fragment each lie in one group
-    constexpr int NSQ = STATS ? 2 : 1;
+    // (NI = 1, the 32-channel layer: groups of 4 channels = one quad each -> one accumulator per quad)
+    constexpr int QSH = NI == 1 ? 0 : 1;            // quads per accumulator = 1 << QSH
+    constexpr int NSQ = STATS ? (4 >> QSH) : 1;
     pc_f32x2 st_s[NI][NSQ], st_ss[NI][NSQ];       // pairs: v_pk_add_f32 / v_pk_fma_f32 straight from the accumulator registers
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -400,16 +450,11 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                         acc[ni][mi][4 * q + j] = 0.f;
                     }
                     if (STATS) {
-#ifdef PC_STATS_NOPK
-                        st_s[ni][q >> 1][0] += (v[0] + v[1]) + (v[2] + v[3]);
-                        st_ss[ni][q >> 1][0] += fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                        continue;
-#endif
                         const pc_f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
-                        st_s[ni][q >> 1] += v01;
-                        st_s[ni][q >> 1] += v23;
-                        st_ss[ni][q >> 1] = __builtin_elementwise_fma(v01, v01, st_ss[ni][q >> 1]);
-                        st_ss[ni][q >> 1] = __builtin_elementwise_fma(v23, v23, st_ss[ni][q >> 1]);
+                        st_s[ni][q >> QSH] += v01;
+                        st_s[ni][q >> QSH] += v23;
+                        st_ss[ni][q >> QSH] = __builtin_elementwise_fma(v01, v01, st_ss[ni][q >> QSH]);
+                        st_ss[ni][q >> QSH] = __builtin_elementwise_fma(v23, v23, st_ss[ni][q >> QSH]);
                     }
                     typedef __attribute__((ext_vector_type(4))) T t4_t;
                     union { t4_t b; u32x2 u; } cv;
@@ -433,7 +478,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int q = 0; q < NSQ; ++q) {
-                int co = bn0 + ni * 32 + 16 * q + 4 * lh;
+                int co = bn0 + ni * 32 + (16 >> (1 - QSH)) * q + 4 * lh;
                 asm volatile("" : "+v"(co));
                 const float s = half_wave_sum(st_s[ni][q][0] + st_s[ni][q][1]), ss = half_wave_sum(st_ss[ni][q][0] + st_ss[ni][q][1]);
                 if (lr == 0) {
@@ -454,7 +499,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
     u32x4 rseen = {0u, 0u, 0u, 0u};
 #pragma unroll 1
     for (int c = 0; c < total; ++c) {
-        pc_wait_ge(ready_p, rseen, c + 1, broken);      // all four staging waves have stored item c
+        pc_wait_ge<NP / 4>(ready_p, rseen, c + 1, broken);      // all four staging waves have stored item c
         PPT_MARK(5)
         const char* buf = smem + bi * kPcBuf;
         bi = bi == kPcStages - 1 ? 0 : bi + 1;
@@ -481,7 +526,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
                 const int idx = tap * NI + ni;
                 if (idx + AD < 9 * NI) load_a(idx + AD);
                 if (ni == 0 && tap + 1 < 9) load_b(tap + 1, (tap + 1) & 1);
-                if (tap == 7 && ni == 0) rseen = pc_peek(ready_p);      // is the next item there?  (answer used at its start)
+                if (tap == 7 && ni == 0) rseen = pc_peek<NP / 4>(ready_p);      // is the next item there?  (answer used at its start)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -498,7 +543,7 @@ __global__ __launch_bounds__(kPcThreads, 2) void conv_pc_kernel(const ConvParams
             const int n_prev = n;
             kc = 0;
             ++tile;
-            if (tile < bt1) decode(tile, n, ty0, tx0);
+            if (tile < bt1) next_tile(n, ty0, tx0);
             if (STATS && (tile >= bt1 || n != n_prev)) flush_stats(n_prev);
             PPT_MARK(4)
         }
@@ -519,37 +564,60 @@ extern "C" int mrisr_debug_phase_cycles(unsigned long long* out96) {
 #endif
 
 // Does this launch take the producer / consumer kernel?  (p: filled by conv_fill_params.)
-bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p) {
+// 0 = no, 4 = 128-channel blocks, 1 = the narrow blend variant (Cout = 32, two activated sources blended by the staging waves)
+int conv_pc_kind(const mrisr_conv_desc* d, const ConvParams& p) {
 #ifdef MRISR_NO_PC
-    return false;
+    return 0;
 #endif
-    if (!d->wpacked_ring) return false;
-    if (d->dtype == MRISR_F32 || d->ksize != 3 || d->Cin % 16 || d->Cout % kPcBN) return false;
-    if (d->out_mode != MRISR_OUT_PLAIN || d->relu_mask || d->combine != MRISR_COMBINE_CONCAT) return false;
-    if (d->nsrc < 1 || d->nsrc > 2) return false;
+    if (!d->wpacked_ring) return 0;
+    if (d->dtype == MRISR_F32 || d->ksize != 3 || d->Cin % 16) return 0;
+    if (d->out_mode != MRISR_OUT_PLAIN || d->relu_mask) return 0;
+    if (d->nsrc < 1 || d->nsrc > 2) return 0;
     for (int i = 0; i < d->nsrc; ++i) {
-        if (d->src[i].spatial != MRISR_SP_NONE) return false;
-        if (d->src[i].mode != d->src[0].mode) return false;
-        if (d->src[i].mode != MRISR_SRC_NORM && d->src[i].mode != MRISR_SRC_RAW) return false;
+        if (d->src[i].spatial != MRISR_SP_NONE) return 0;
+        if (d->src[i].mode != d->src[0].mode) return 0;
+        if (d->src[i].mode != MRISR_SRC_NORM && d->src[i].mode != MRISR_SRC_RAW) return 0;
     }
-    if (d->nsrc == 2 && (d->src[0].C % 16)) return false;           // a 16-channel chunk lies in one source
+    for (int i = 0; i < d->nsrc; ++i)                               // 32-bit byte offsets into each source (buffer loads)
+        if ((unsigned long long)d->N * d->src[i].H * d->src[i].W * d->src[i].C * 2ull >= (1ull << 31)) return 0;
+    if (d->H % 8 || d->W % 32) return 0;                            // whole 8 x 32 tiles only (unpredicated stores)
+    const int tiles = d->N * (d->H / 8) * (d->W / 32);
+    if (d->combine == MRISR_COMBINE_BLEND) {
+        // final_conv.0 without the materialised blend (eval forward): 32 output channels, two activated sources of the conv's
+        // own geometry; GroupNorm groups of 4 channels = one accumulator quad each
+        if (d->Cout != 32 || d->nsrc != 2 || d->src[0].mode != MRISR_SRC_NORM || !d->blend_alpha) return 0;
+        for (int i = 0; i < 2; ++i)
+            if (d->src[i].C != d->Cin || d->src[i].H != d->H || d->src[i].W != d->W || d->src[i].off_y || d->src[i].off_x) return 0;
+        if (d->stats && (d->Cout / d->groups) % 4) return 0;
+        return (long)tiles * 4 >= (long)p.cus * 3 ? 1 : 0;
+    }
+    if (d->combine != MRISR_COMBINE_CONCAT || d->Cout % kPcBN) return 0;
+    if (d->nsrc == 2 && (d->src[0].C % 16)) return 0;               // a 16-channel chunk lies in one source
     // stored sources: the LDS-DMA kernels stage them without any vector work; this kernel wins from 128 input channels on
     // (8 items per tile epilogue; 128 -> 64 input gradient at 256^2: 171 vs 162 us)
-    if (d->src[0].mode == MRISR_SRC_RAW && d->Cin < 128) return false;
-    for (int i = 0; i < d->nsrc; ++i)                               // 32-bit byte offsets into each source (buffer loads)
-        if ((unsigned long long)d->N * d->src[i].H * d->src[i].W * d->src[i].C * 2ull >= (1ull << 31)) return false;
-    if (d->stats && ((d->Cout / d->groups) & 15)) return false;     // a GroupNorm group spans whole 16-channel quad pairs
-    if (d->H % 8 || d->W % 32) return false;                        // whole 8 x 32 tiles only (unpredicated stores)
-    const int tiles = d->N * (d->H / 8) * (d->W / 32);
+    if (d->src[0].mode == MRISR_SRC_RAW && d->Cin < 128) return 0;
+    if (d->stats && ((d->Cout / d->groups) & 15)) return 0;         // a GroupNorm group spans whole 16-channel quad pairs
     const int ncb = d->Cout / kPcBN;
-    return (long)tiles * ncb * 4 >= (long)p.cus * 3;                // >= 0.75 work items per CU
+    return (long)tiles * ncb * 4 >= (long)p.cus * 3 ? 4 : 0;        // >= 0.75 work items per CU
+}
+bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p) { return conv_pc_kind(d, p) != 0; }
+
+template <typename T, bool NORM, bool STATS, int NI, bool BLEND>
+static void launch_pc_k(const ConvParams& p, int grid, hipStream_t s) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, NORM, STATS, NI, BLEND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((conv_pc_kernel<T, NORM, STATS, NI, BLEND>), dim3(grid), dim3(pc_threads(BLEND)), pc_lds(NI, pc_np(BLEND)), s, p);
 }
 
 template <typename T>
 static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s) {
+    const int kind = conv_pc_kind(d, cp);
+    const int bn = kind == 1 ? 32 : kPcBN;
     ConvParams p = cp;
     p.wpacked = d->wpacked_ring;
-    p.nchunks = d->Cin / 16; p.ncb = d->Cout / kPcBN;
+    p.nchunks = d->Cin / 16; p.ncb = d->Cout / bn;
     p.tiles_x = d->W / 32; p.tiles_y = d->H / 8;
     p.ntiles = d->N * p.tiles_x * p.tiles_y;
     p.groups = d->stats ? d->groups : 0;
@@ -559,19 +627,14 @@ static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream
     p.tiles_per_block = ceil_div(p.ntiles, per_cb);
     per_cb = ceil_div(p.ntiles, p.tiles_per_block);
     const int grid = per_cb * p.ncb;
-    const size_t lds = kPcLds;
     const bool norm = d->src[0].mode == MRISR_SRC_NORM, stats = d->stats != nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (norm && stats) hipLaunchKernelGGL((conv_pc_kernel<T, true, true>), dim3(grid), dim3(kPcThreads), lds, s, p);
-    else if (norm) hipLaunchKernelGGL((conv_pc_kernel<T, true, false>), dim3(grid), dim3(kPcThreads), lds, s, p);
-    else if (stats) hipLaunchKernelGGL((conv_pc_kernel<T, false, true>), dim3(grid), dim3(kPcThreads), lds, s, p);
-    else hipLaunchKernelGGL((conv_pc_kernel<T, false, false>), dim3(grid), dim3(kPcThreads), lds, s, p);
+    if (kind == 1) {
+        if (stats) launch_pc_k<T, true, true, 1, true>(p, grid, s);
+        else launch_pc_k<T, true, false, 1, true>(p, grid, s);
+    } else if (norm && stats) launch_pc_k<T, true, true, 4, false>(p, grid, s);
+    else if (norm) launch_pc_k<T, true, false, 4, false>(p, grid, s);
+    else if (stats) launch_pc_k<T, false, true, 4, false>(p, grid, s);
+    else launch_pc_k<T, false, false, 4, false>(p, grid, s);
     MRISR_CHECK_LAUNCH("conv_forward(pc)");
     return MRISR_OK;
 }

@@ -454,7 +454,7 @@ bool conv_ring_eligible(const mrisr_conv_desc* d, const ConvParams& p) {
     return false;
 #endif
     if (!d->wpacked_ring) return false;
-    if (!mrisr_conv_ring_bn(d->dtype, d->Cout, d->Cin, d->ksize)) return false;
+    if (mrisr_conv_ring_bn(d->dtype, d->Cout, d->Cin, d->ksize) != 128) return false;
     if (d->Cin < 256) return false;      // the ring pays from 256 input channels on (profiles/r03_ring_kernel.txt)
     if (d->out_mode != MRISR_OUT_PLAIN || d->relu_mask || d->combine != MRISR_COMBINE_CONCAT) return false;
     if (d->nsrc != 1 || d->src[0].mode != MRISR_SRC_RAW || d->src[0].spatial != MRISR_SP_NONE) return false;

@@ -261,13 +261,13 @@ class UNetEngine:
         self._packed_token = (dt, token)
 
     # ------------------------------------------------------------------ descriptors
-    def _desc(self, layer: Layer, dt: int, N: int, params) -> L.ConvDesc:
+    def _desc(self, layer: Layer, dt: int, N: int, params, fused_blend: bool = False) -> L.ConvDesc:
         d = L.ConvDesc()
         d.dtype, d.N, d.H, d.W = dt, N, layer.H, layer.W
         d.Cin, d.Cout, d.ksize, d.nsrc = layer.cin, layer.cout, layer.ks, len(layer.srcs)
         d.combine, d.out_mode, d.groups, d.relu_out = layer.combine, layer.out_mode, GN_GROUPS, 0
         d.cu_limit = _CU_LIMIT
-        if layer.blend_src:                         # materialised blend: one plain source
+        if layer.blend_src and not fused_blend:     # materialised blend: one plain source
             d.nsrc, d.combine = 1, L.COMBINE_CONCAT
             d.src[0].ptr = layer.aux.data_ptr()
             d.src[0].C, d.src[0].H, d.src[0].W = layer.cin, layer.H, layer.W
@@ -353,7 +353,12 @@ class UNetEngine:
                 layer.aux = torch.empty((N, vh, vw, sn.C), dtype=dtype, device=dev)
                 L.call("mrisr_norm_upsample2", dt, sn.raw.data_ptr(), sn.scale.data_ptr(), sn.shift.data_ptr(),
                        layer.aux.data_ptr(), N, sn.H, sn.W, sn.C, st, nbytes=N * sn.H * sn.W * sn.C * es * 5)
-            if layer.blend_src:
+            # eval forward, 16-bit storage: the blend is formed by the staging waves of conv_pc_kernel<..., NI = 1, BLEND> - the
+            # blended tensor (268 MB at the headline shapes: 158 us to write it, then read again by the conv) never exists.
+            # Training keeps it: the layer's weight gradient reads it.
+            fused_blend = (layer.blend_src and not training and es == 2 and not TUNING.no_fused_blend
+                           and (layer.name, dt, 0, "ring") in self._packed)
+            if layer.blend_src and not fused_blend:
                 a, b = layer.srcs[0].node, layer.srcs[1].node
                 if (a.H, a.W, a.C) != (b.H, b.W, b.C):
                     raise RuntimeError(f"{layer.name}: blend sources differ in shape")
@@ -376,7 +381,7 @@ class UNetEngine:
             else:
                 o.H, o.W = vh, vw
             o.raw = torch.empty((N, o.H, o.W, o.C), dtype=dtype, device=dev)
-            d = self._desc(layer, dt, N, params)
+            d = self._desc(layer, dt, N, params, fused_blend)
             d.wpacked = self._packed[(layer.name, dt, 0)].data_ptr()
             d.wpacked_ring = L.ptr(self._packed.get((layer.name, dt, 0, "ring")))
             d.bias = params[layer.name + ".bias"].data_ptr() if layer.bias else None

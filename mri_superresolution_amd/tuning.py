@@ -15,6 +15,8 @@ that `tools/` can A/B schedules on one box without editing the package.  libmris
   MRISR_UP_FUSED       1: the decoder's 1x1 conv + bilinear x2 + statistics run as ONE launch (csrc/up_fused.hip) instead of the
                        default two (mrisr_conv_forward at low resolution = csrc/conv1x1.hip's GEMM, + mrisr_upsample2_stats):
                        the fused form was +0.2-0.3 % over the classic 1x1 kernel, the GEMM is +0.5 % over the fused form
+  MRISR_NO_FUSED_BLEND 1: the eval forward materialises the alpha blend in front of final_conv.0 (mrisr_norm_blend) as the training
+                       forward does, instead of forming it in the staging waves of conv_pc_kernel
   MRISR_NO_ONEPASS     1: every GroupNorm backward runs as two launches (reduce + apply) instead of the one-pass kernel with the
                        in-kernel image barrier (csrc/norm.hip: act_bwd_onepass_kernel)
   MRISR_FORCE_DP       1: bench.py / scripts wrap the model in DataParallel even at world size 1 (rehearses the RCCL path)
@@ -47,6 +49,7 @@ class Tuning:
     no_ring: bool
     up_fused: bool
     no_onepass: bool
+    no_fused_blend: bool
 
 
 def _read() -> Tuning:
@@ -61,6 +64,7 @@ def _read() -> Tuning:
         no_ring=_int("MRISR_NO_RING", 0) == 1,
         up_fused=_int("MRISR_UP_FUSED", 0) == 1,
         no_onepass=_int("MRISR_NO_ONEPASS", 0) == 1,
+        no_fused_blend=_int("MRISR_NO_FUSED_BLEND", 0) == 1,
     )
 
 

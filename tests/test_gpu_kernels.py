@@ -222,6 +222,38 @@ def test_conv1x1_gemm(dt, case):
     assert U.relerr(out, out2) <= TOL_OUT[dt]
 
 
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("case", ["head", "two_images_multi_tile"])
+def test_conv_pc_blend_narrow(dt, case):
+    """conv_pc_kernel<..., NI = 1, BLEND>: final_conv.0 of the eval forward (unet_model.py:206-209) - 32 output channels, the input
+    sigmoid(alpha) * act(bilinear branch) + (1 - sigmoid(alpha)) * act(pixel-shuffle branch) formed by the staging waves,
+    GroupNorm statistics over groups of 4 channels - against torch's conv on the blended activations and against the classic
+    blend-loader kernel."""
+    n, h, w = {"head": (8, 64, 96), "two_images_multi_tile": (2, 128, 256)}[case]
+    cin = cout = 32
+    wt = rnd(cout, cin, 3, 3, seed=170, scale=0.1)
+    alpha = torch.tensor(0.3)
+    srcs = []
+    for i in range(2):
+        x = rnd(n, cin, h, w, seed=171 + i)
+        sc, sh = gn_affine(n, cin, 173 + i)
+        srcs.append(U.SrcSpec(x, L.SRC_NORM, L.SP_NONE, sc, sh))
+    ran = []
+    out, stats = U.conv_forward(dt, srcs, wt, h, w, 3, combine=L.COMBINE_BLEND, alpha=alpha, variant=ran)
+    assert ran[0].startswith("conv_pc_kernel<"), ran
+    ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w, L.COMBINE_BLEND, alpha), U.rounded(wt, dt), padding=1)
+    assert torch.isfinite(out).all()
+    assert U.relerr(out, ref) <= TOL_NORM[dt]
+    o = ref.view(n, 8, cout // 8, h, w).double()
+    assert torch.allclose(stats[..., 0], o.sum((2, 3, 4)), rtol=1e-4, atol=1e-4 * o.abs().sum((2, 3, 4)).max().item())
+    assert torch.allclose(stats[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-3)
+    ran2 = []
+    out2, stats2 = U.conv_forward(dt, srcs, wt, h, w, 3, combine=L.COMBINE_BLEND, alpha=alpha, use_ring=False, variant=ran2)
+    assert ran2[0].startswith("conv_igemm_kernel<"), ran2
+    assert U.relerr(out, out2) <= TOL_OUT[dt]
+    assert torch.allclose(stats, stats2, rtol=1e-3, atol=1e-3 * float(stats2.abs().max()))
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv1x1_and_bias(dt):
     n, cin, cout, h, w = 2, 64, 32, 20, 36
