@@ -237,18 +237,6 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
 #pragma unroll
             for (int j = 0; j < kPcWSlots; ++j)
                 S.w[j] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(wv + 16u * PT * j), woff, 0);
-#ifdef PC_GLOBAL_AFF
-            if (NORM) {
-                const float* scp = (w1 ? p.src[1].scale : p.src[0].scale) + (size_t)n * Cs + cs + lslot * VEC;
-                const float* shp = (w1 ? p.src[1].shift : p.src[0].shift) + (size_t)n * Cs + cs + lslot * VEC;
-#pragma unroll
-                for (int e = 0; e < VEC; e += 4) {
-                    const f32x4 a = gload<f32x4>(scp + e), b = gload<f32x4>(shp + e);
-                    S.sc[e / 2] = pc_f32x2{a[0], a[1]}; S.sc[e / 2 + 1] = pc_f32x2{a[2], a[3]};
-                    S.sh[e / 2] = pc_f32x2{b[0], b[1]}; S.sh[e / 2 + 1] = pc_f32x2{b[2], b[3]};
-                }
-            }
-#else
             if (NORM) {
                 const int aoff = (n * Cs + cs) * 4;
                 const __amdgpu_buffer_rsrc_t scr = w1 ? sc_rsrc1 : sc_rsrc0, shr = w1 ? sh_rsrc1 : sh_rsrc0;
@@ -266,7 +254,6 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
                     }
                 }
             }
-#endif
             S.ty0 = ty0; S.tx0 = tx0; S.w1 = w1 ? 1 : 0;
         };
         PPT_DECL
