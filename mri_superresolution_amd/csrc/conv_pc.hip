@@ -264,6 +264,35 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
             int q = pt;
             asm volatile("" : "+v"(q));
             const int pty0 = S.ty0, ptx0 = S.tx0, pw1 = S.w1;
+            // Edge tiles: which of this thread's halo slots lie outside the source (conv padding; their loads aliased into
+            // neighbouring rows) - 4 bits per slot, applied as a SELECT in front of the one LDS store of the slot.  (A second,
+            // exec-masked store of zeros behind the main one was not safe with counter hand-over: an MFMA wave that reacted
+            // within ~100 cycles of the ready flag read the aliased value at plane-edge columns - sparse stores of a wave
+            // are not guaranteed to be visible to OTHER waves in issue order; profiles/NOTES.md R3-11.)
+            unsigned hit = 0;
+            {
+                const bool w1 = pw1 != 0;
+                const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W;
+                const int ys0 = pty0 - 1 - (w1 ? p.src[1].off_y : p.src[0].off_y), xs0 = ptx0 - 1 - (w1 ? p.src[1].off_x : p.src[0].off_x);
+                const bool interior = ys0 >= 0 && xs0 >= 0 && ys0 + kPcHaloH <= Hs && xs0 + kPcHaloW <= Ws;
+                if (!interior) {
+                    // at most the outermost halo ring lies outside (every layer of the network: the source covers the plane):
+                    // the tile's four edge bits against the slots' precomputed ones
+                    const bool ring_only = ys0 >= -1 && xs0 >= -1 && ys0 + kPcHaloH <= Hs + 1 && xs0 + kPcHaloW <= Ws + 1;
+                    if (ring_only) {
+                        const unsigned tm = (ys0 < 0 ? 1u : 0u) | (ys0 + kPcHaloH > Hs ? 2u : 0u) | (xs0 < 0 ? 4u : 0u) | (xs0 + kPcHaloW > Ws ? 8u : 0u);
+                        hit = fflags & (tm * 0x111u);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kPcHaloSlots; ++j) {
+                            const int row = (q >> 1) + (PT / 2) * j;
+                            const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;
+                            const unsigned y = ys0 + hy, x = xs0 + hx;
+                            if (row < kPcHaloRows && !(y < (unsigned)Hs && x < (unsigned)Ws)) hit |= 0xfu << (4 * j);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kPcHaloSlots; ++j) {
                 Vec16<T> v = S.h[j];
@@ -287,6 +316,13 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
                         v.set(e + 1, fmaxf(yb, LRELU_SLOPE * yb));
                     }
                 }
+                {
+                    const bool zero = (hit & (0xfu << (4 * j))) != 0;
+                    u32x4 bits = __builtin_bit_cast(u32x4, v.v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bits[e] = zero ? 0u : bits[e];
+                    v.v = __builtin_bit_cast(decltype(v.v), bits);
+                }
                 *reinterpret_cast<decltype(v.v)*>(lds_h + (q + PT * j) * 16) = v.v;
             }
             PPT_MARK(0)
@@ -295,34 +331,6 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
             PPT_MARK(1)
             issue(S, n, ty0, tx0, kc);
             PPT_MARK(3)
-            // edge tiles: zeros over the halo pixels outside the source (conv padding)
-            const bool w1 = pw1 != 0;
-            const int Hs = w1 ? p.src[1].H : p.src[0].H, Ws = w1 ? p.src[1].W : p.src[0].W;
-            const int ys0 = pty0 - 1 - (w1 ? p.src[1].off_y : p.src[0].off_y), xs0 = ptx0 - 1 - (w1 ? p.src[1].off_x : p.src[0].off_x);
-            const bool interior = ys0 >= 0 && xs0 >= 0 && ys0 + kPcHaloH <= Hs && xs0 + kPcHaloW <= Ws;
-            if (!interior) {
-                Vec16<T> z;
-                z.zero();
-                // at most the outermost halo ring lies outside (every layer of the network: the source covers the plane): the
-                // tile's four edge bits against the slots' precomputed ones
-                const bool ring_only = ys0 >= -1 && xs0 >= -1 && ys0 + kPcHaloH <= Hs + 1 && xs0 + kPcHaloW <= Ws + 1;
-                if (ring_only) {
-                    const unsigned tm = (ys0 < 0 ? 1u : 0u) | (ys0 + kPcHaloH > Hs ? 2u : 0u) | (xs0 < 0 ? 4u : 0u) | (xs0 + kPcHaloW > Ws ? 8u : 0u);
-                    const unsigned hit = fflags & (tm * 0x111u);
-#pragma unroll
-                    for (int j = 0; j < kPcHaloSlots; ++j)
-                        if (hit & (0xfu << (4 * j))) *reinterpret_cast<decltype(z.v)*>(lds_h + (q + PT * j) * 16) = z.v;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kPcHaloSlots; ++j) {
-                        const int row = (q >> 1) + (PT / 2) * j;
-                        const int hy = (row * 1928) >> 16, hx = row - hy * kPcHaloW;
-                        const unsigned y = ys0 + hy, x = xs0 + hx;
-                        if (row < kPcHaloRows && !(y < (unsigned)Hs && x < (unsigned)Ws))
-                            *reinterpret_cast<decltype(z.v)*>(lds_h + (q + PT * j) * 16) = z.v;
-                    }
-                }
-            }
         };
 
         // item cursor of the loads (runs three items ahead of the MFMAs; past the end it stays on the last item: the tail
@@ -513,7 +521,10 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
                 const int idx = tap * NI + ni;
                 if (idx + AD < 9 * NI) load_a(idx + AD);
                 if (ni == 0 && tap + 1 < 9) load_b(tap + 1, (tap + 1) & 1);
-                if (tap == 7 && ni == 0) rseen = pc_peek<NP / 4>(ready_p);      // is the next item there?  (answer used at its start)
+                // is the next item there?  (the answer is used at its start, ~1000 cycles later: late-round experiments with polls that
+                // react within ~100 cycles of a flag showed stale operands up to ~300 cycles behind it - profiles/NOTES.md R3-11 - so the
+                // snapshot is taken early on purpose)
+                if (tap == 5 && ni == 0) rseen = pc_peek<NP / 4>(ready_p);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
