@@ -76,16 +76,20 @@ __device__ __forceinline__ void pc_signal(unsigned lds_addr) {
 }
 // (the polls are volatile LDS loads, not asm: hipcc's own `s_waitcnt lgkmcnt` bookkeeping must see every LDS operation)
 __device__ __forceinline__ int pc_min4(const u32x4 v) { return min(min((int)v[0], (int)v[1]), min((int)v[2], (int)v[3])); }
-// NV vectors of four counters, element-wise minimum
+// Four counters.  RELAXED WORKGROUP-scope atomic loads through an explicit LDS (address space 3) pointer: plain `ds_read_b32`s
+// that hipcc tracks on lgkmcnt and waits for at their first use.  (A `volatile` load through the generic pointer compiled to
+// `flat_load_dwordx4 ... sc0 sc1` + `s_waitcnt vmcnt(0)`: every peek of the staging waves waited for ALL their outstanding
+// global loads, and - a FLAT instruction inside the polling loop - made the wait-count pass emit `vmcnt(0)` behind the loop.)
 template <int NV>
 __device__ __forceinline__ u32x4 pc_peek(const unsigned* cnt) {
-    u32x4 m = *reinterpret_cast<const volatile u32x4*>(cnt);
-#pragma unroll
-    for (int i = 1; i < NV; ++i) {
-        const u32x4 v = *reinterpret_cast<const volatile u32x4*>(cnt + 4 * i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = min(m[e], v[e]);
-    }
+    static_assert(NV == 1, "four counters");
+    typedef const __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* c3 = (lds_u32*)cnt;
+    u32x4 m;
+    m[0] = __hip_atomic_load(c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    m[1] = __hip_atomic_load(c3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    m[2] = __hip_atomic_load(c3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    m[3] = __hip_atomic_load(c3 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return m;
 }
 // `seen`: a peek taken earlier (the answer is usually already there: no LDS round trip on the critical path)
@@ -521,10 +525,7 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
                 const int idx = tap * NI + ni;
                 if (idx + AD < 9 * NI) load_a(idx + AD);
                 if (ni == 0 && tap + 1 < 9) load_b(tap + 1, (tap + 1) & 1);
-                // is the next item there?  (the answer is used at its start, ~1000 cycles later: late-round experiments with polls that
-                // react within ~100 cycles of a flag showed stale operands up to ~300 cycles behind it - profiles/NOTES.md R3-11 - so the
-                // snapshot is taken early on purpose)
-                if (tap == 5 && ni == 0) rseen = pc_peek<NP / 4>(ready_p);
+                if (tap == 6 && ni == 0) rseen = pc_peek<NP / 4>(ready_p);      // is the next item there?  (answer used at its start)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
