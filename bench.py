@@ -398,7 +398,7 @@ def main():
                                    "timing": f"the dominant kernel is picked among the live-timed CONVOLUTION kernels; HIP events on the launch stream, separate pass of {timed_steps} steps "
                                              f"({timed_elapsed / timed_steps * 1e3:.3f} ms/step instrumented), ONE stream, "
                                              "every persistent kernel sized for the whole chip (the headline region runs "
-                                             "the weight gradients on a second stream sized for 3/8 of the CUs); a "
+                                             "the weight gradients on a second stream sized for 13/32 of the CUs); a "
                                              "conv_wgrad entry = the weight-gradient kernel + its split-K reduce kernel timed "
                                              "as one unit; rocprofv3 counterpart: "
                                              "profiles/r03_step_kernel_stats_single_stream.csv"}

@@ -566,7 +566,12 @@ class UNetEngine:
         # second stream for the weight gradients (not while kernels are being timed with events on the main stream)
         side = None
         main = torch.cuda.current_stream()
-        side_cus = L.num_cus() * 3 // 8 if _WGRAD_CUS < 0 else _WGRAD_CUS
+        # default split, measured with the round-3 kernels (tools/sweep_wgrad_cus.sh, tools/c5_cus.sh; both keep the main stream's
+        # persistent grids a multiple of 8 workgroups for the XCD-aware order - 108 of 256 CUs costs 3 %): 13/32 of the chip at the
+        # headline width (f <= 64: 104 CUs 8.00-8.03 ms against 8.12 at 96 and 8.05 at 112), 3/8 for wider models (f = 128, depth 5:
+        # 96 CUs 54.8 ms against 55.6 at 104)
+        side_default = L.num_cus() * 13 // 32 if self.f <= 64 else L.num_cus() * 3 // 8
+        side_cus = side_default if _WGRAD_CUS < 0 else _WGRAD_CUS
         if _WGRAD_STREAM and self.timer is None:
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != dev:

@@ -6,7 +6,7 @@ that `tools/` can A/B schedules on one box without editing the package.  libmris
   MRISR_LIB            path of an alternative libmrisr.so build (A/B of kernel variants); it must pass the same ABI-version
                        and symbol checks as the in-tree library
   MRISR_WGRAD_STREAM   1 (default): weight-gradient kernels on a second, high-priority HIP stream; 0: one stream
-  MRISR_WGRAD_CUS      CUs the second stream's kernels are sized for; -1 (default) = 3/8 of the chip, 0 = no split
+  MRISR_WGRAD_CUS      CUs the second stream's kernels are sized for; -1 (default) = 13/32 of the chip (3/8 for base_filters > 64), 0 = no split
   MRISR_WGRAD_LAST     1: input gradient before weight gradient inside a layer's backward step (default 0)
   MRISR_CU_LIMIT       size every persistent convolution for this many CUs (0 = whole chip)
   MRISR_SIDE_PRIO      priority of the second stream (default -1 = high: its own hardware queue class)
