@@ -38,8 +38,8 @@ ENTRY_KERNEL = {"mrisr_act_bwd_onepass": "act_bwd_onepass_kernel", "mrisr_act_bw
                 "mrisr_act_bwd_apply_fused_unshuffle": "act_bwd_unshuffle_window_kernel", "mrisr_act_bwd_apply": "act_bwd_apply_kernel",
                 "mrisr_norm_pool2": "norm_pool2_kernel", "mrisr_norm_upsample2": "norm_upsample2_kernel",
                 "mrisr_norm_blend": "norm_blend_kernel", "mrisr_upsample2_stats": "upsample2_stats_kernel",
-                "mrisr_upsample2_adjoint": "upsample2_adjoint_kernel", "mrisr_head_forward": "head_fwd_kernel",
-                "mrisr_stem_forward": "stem_fwd_kernel", "mrisr_stem_wgrad": "stem_wgrad_kernel",
+                "mrisr_upsample2_adjoint": "upsample2_adjoint_kernel", "mrisr_head_forward_multi": "head_fwd_kernel",
+                "mrisr_stem_forward_multi": "stem_fwd_kernel", "mrisr_stem_wgrad_multi": "stem_wgrad_kernel",
                 "mrisr_ssim_l1_forward": "ssim_l1_fwd_kernel", "mrisr_ssim_l1_backward": "ssim_l1_bwd_kernel",
                 "mrisr_adam_step": "adam_kernel", "mrisr_adam_step_amp": "adam_amp_kernel",
                 "mrisr_pack_weights_batched": "pack_weights_batched_kernel", "mrisr_channel_sum": "channel_sum_kernel"}

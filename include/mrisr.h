@@ -145,6 +145,12 @@ int mrisr_stem_forward(int dtype, const float* x, const float* w, void* out, dou
                        int N, int H, int W, int Cout, int groups, void* stream);
 int mrisr_stem_wgrad(int dtype, const float* x, const void* dy, float* dw,
                      int N, int H, int W, int Cout, void* stream);
+/* the same for 1 <= Cin <= 4 image channels (UNetSuperRes(in_channels=...), unet_model.py:129,137): x fp32 NCHW
+ * [N][Cin][H][W], w / dw fp32 [Cout][9][Cin] (the channels-last storage every conv weight has on this side)  */
+int mrisr_stem_forward_multi(int dtype, const float* x, const float* w, void* out, double* stats,
+                             int N, int H, int W, int Cin, int Cout, int groups, void* stream);
+int mrisr_stem_wgrad_multi(int dtype, const float* x, const void* dy, float* dw,
+                           int N, int H, int W, int Cin, int Cout, void* stream);
 
 /* ---- GroupNorm(8,C)+LeakyReLU(0.2): statistics -> per-(n,c) affine (unet_model.py:30-31) -- */
 /* stats [MRISR_STAT_SLOTS][N][G][2] double -> scale/shift [N][C] fp32, meanrstd [N][G][2] fp32; count = (C/G)*H*W */
@@ -279,6 +285,14 @@ int mrisr_head_forward(int dtype, const void* x, const float* scale, const float
 int mrisr_head_backward(int dtype, const void* x, const float* scale, const float* shift,
                         const float* w, const float* out, const float* dout, void* da, float* dw,
                         float* db, int N, int H, int W, int C, void* stream);
+/* the same for 1 <= K <= 4 output channels (UNetSuperRes(out_channels=...), unet_model.py:129,172): w [K][C], b [K],
+ * out / dout fp32 NCHW [N][K][H][W]; dw [K][C], db [K]                                                        */
+int mrisr_head_forward_multi(int dtype, const void* x, const float* scale, const float* shift,
+                             const float* w, const float* b, float* out, int N, int H, int W, int C,
+                             int K, void* stream);
+int mrisr_head_backward_multi(int dtype, const void* x, const float* scale, const float* shift,
+                              const float* w, const float* out, const float* dout, void* da,
+                              float* dw, float* db, int N, int H, int W, int C, int K, void* stream);
 
 /* ---- loss: fused L1 + Gaussian-window SSIM (utils/losses.py:27-81,200-226) ---------------- */
 /* a, b: [N][H][W] fp32 (single channel), 11-tap window.  sums[N][2] (double, accumulated):

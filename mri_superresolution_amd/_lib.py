@@ -79,6 +79,8 @@ SIGNATURES = {
     "mrisr_conv_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc)]),
     "mrisr_stem_forward": (_i, [_i, _fp, _fp, _vp, _dp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_stem_wgrad": (_i, [_i, _fp, _vp, _fp, _i, _i, _i, _i, _vp]),
+    "mrisr_stem_forward_multi": (_i, [_i, _fp, _fp, _vp, _dp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_stem_wgrad_multi": (_i, [_i, _fp, _vp, _fp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_gn_finalize": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _d, _f, _vp]),
     "mrisr_norm_pool2": (_i, [_i, _vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
     "mrisr_norm_upsample2": (_i, [_i, _vp, _fp, _fp, _vp, _i, _i, _i, _i, _vp]),
@@ -102,6 +104,8 @@ SIGNATURES = {
     "mrisr_blend_alpha_grad": (_i, [_i, _vp, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mrisr_head_forward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mrisr_head_backward": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mrisr_head_forward_multi": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "mrisr_head_backward_multi": (_i, [_i, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "mrisr_ssim_l1_forward": (_i, [_fp, _fp, _dp, _fp, _i, _i, _i, _f, _f, _vp]),
     "mrisr_ssim_l1_backward": (_i, [_fp, _fp, _fp, _dp, _fp, _f, _f, _fp, _i, _i, _i, _f, _vp]),
     "mrisr_ssim_l1_forward_win": (_i, [_fp, _fp, _dp, _fp, _i, _i, _i, _f, _f, _i, _vp]),
@@ -124,7 +128,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 303      # mrisr_version() of the library these struct layouts and signatures belong to
+ABI_VERSION = 304      # mrisr_version() of the library these struct layouts and signatures belong to
 
 
 def load():

@@ -141,9 +141,11 @@ class UNetEngine:
     channels_last storage, i.e. physically [Cout][kh][kw][Cin]); ``grads``: same keys."""
 
     def __init__(self, base_filters: int, in_channels: int = 1, out_channels: int = 1, depth: int = 4):
-        if in_channels != 1 or out_channels != 1:
-            raise NotImplementedError("the HIP path implements the reference's 1->1 channel configuration "
-                                      "(scripts/train.py:167-173, scripts/infer.py:46-51)")
+        # 1 -> 1 is the reference's own configuration (scripts/train.py:167-173, scripts/infer.py:46-51) and the tuned one; the two
+        # narrow ends of the network take up to four image channels each (unet_model.py:129: e.g. RGB) through the same kernels
+        if not (1 <= in_channels <= 4 and 1 <= out_channels <= 4):
+            raise NotImplementedError("the HIP stem / head kernels take 1..4 image channels (in_channels, out_channels)")
+        self.cin, self.cout = in_channels, out_channels
         if base_filters % 16:
             raise ValueError("base_filters must be a multiple of 16 (GroupNorm(8, base_filters // 2))")
         f = self.f = base_filters
@@ -301,7 +303,7 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, params, x: torch.Tensor, dtype: torch.dtype, training: bool, weights_token=None):
-        """x: (N,1,H,W) fp32 contiguous on the GPU.  Returns (out (N,1,2H,2W) fp32, ctx).
+        """x: (N,Cin,H,W) fp32 contiguous on the GPU.  Returns (out (N,Cout,2H,2W) fp32, ctx).
         ``weights_token``: any hashable that changes whenever a parameter value may have changed (see _pack_all)."""
         dt = _dt(dtype)
         dev = x.device
@@ -334,8 +336,9 @@ class UNetEngine:
         s = self.stem
         s.N, s.H, s.W = N, H, W
         s.raw = torch.empty((N, H, W, f), dtype=dtype, device=dev)
-        L.call("mrisr_stem_forward", dt, x.data_ptr(), params["inc.double_conv.0.weight"].data_ptr(),
-               s.raw.data_ptr(), s.stats.data_ptr(), N, H, W, f, GN_GROUPS, st, nbytes=N * H * W * (4 + f * es))
+        L.call("mrisr_stem_forward_multi", dt, x.data_ptr(), params["inc.double_conv.0.weight"].data_ptr(),
+               s.raw.data_ptr(), s.stats.data_ptr(), N, H, W, self.cin, f, GN_GROUPS, st,
+               nbytes=N * H * W * (4 * self.cin + f * es))
         finalize(s)
 
         for layer in self.layers:
@@ -412,10 +415,10 @@ class UNetEngine:
             finalize(o)
 
         hn = self.head_in
-        out = torch.empty((N, 1, hn.H, hn.W), dtype=torch.float32, device=dev)
-        L.call("mrisr_head_forward", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
+        out = torch.empty((N, self.cout, hn.H, hn.W), dtype=torch.float32, device=dev)
+        L.call("mrisr_head_forward_multi", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
                params["final_conv.3.weight"].data_ptr(), params["final_conv.3.bias"].data_ptr(), out.data_ptr(),
-               N, hn.H, hn.W, hn.C, st, nbytes=N * hn.H * hn.W * (hn.C * es + 4))
+               N, hn.H, hn.W, hn.C, self.cout, st, nbytes=N * hn.H * hn.W * (hn.C * es + 4 * self.cout))
         ctx = None
         if training:
             ctx = {"x": x, "out": out, "dtype": dtype, "N": N, "arena": arena,
@@ -560,8 +563,17 @@ class UNetEngine:
         # one-channel dz = dout * out * (1 - out), and the first pass accumulates the head's dW / db
         hn = self.head_in
         ho = red_off[hn.name][0] + SL * N * hn.C * 2 + 256 + narr
-        hn.consumers.append((dout, hn.C, 0, hn.H, hn.W, L.SP_HEAD, 0, 0, 0, ctx["out"], params["final_conv.3.weight"],
-                             red_arena[ho:ho + N * (hn.C + 1)], grads["final_conv.3.weight"], grads["final_conv.3.bias"]))
+        if self.cout == 1:
+            hn.consumers.append((dout, hn.C, 0, hn.H, hn.W, L.SP_HEAD, 0, 0, 0, ctx["out"], params["final_conv.3.weight"],
+                                 red_arena[ho:ho + N * (hn.C + 1)], grads["final_conv.3.weight"], grads["final_conv.3.bias"]))
+        else:
+            # several output channels: dL/dact = sum_k dz[k] * w[k] is materialised by the head's own backward kernel
+            dah = torch.empty_like(hn.raw)
+            L.call("mrisr_head_backward_multi", dt, hn.raw.data_ptr(), hn.scale.data_ptr(), hn.shift.data_ptr(),
+                   params["final_conv.3.weight"].data_ptr(), ctx["out"].data_ptr(), dout.data_ptr(), dah.data_ptr(),
+                   grads["final_conv.3.weight"].data_ptr(), grads["final_conv.3.bias"].data_ptr(), N, hn.H, hn.W, hn.C,
+                   self.cout, st, nbytes=N * hn.H * hn.W * (2 * hn.C * es + 8 * self.cout))
+            hn.consumers.append((dah, hn.C, 0, hn.H, hn.W, L.SP_NONE, 0, 0, 0))
 
         # second stream for the weight gradients (not while kernels are being timed with events on the main stream)
         side = None
@@ -667,8 +679,9 @@ class UNetEngine:
 
         # stem (no input gradient: the image needs none)
         dy = node_backward(self.stem)
-        L.call("mrisr_stem_wgrad", dt, x.data_ptr(), dy.data_ptr(), grads["inc.double_conv.0.weight"].data_ptr(),
-               N, self.stem.H, self.stem.W, self.f, st, nbytes=N * self.stem.H * self.stem.W * (4 + self.f * es))
+        L.call("mrisr_stem_wgrad_multi", dt, x.data_ptr(), dy.data_ptr(), grads["inc.double_conv.0.weight"].data_ptr(),
+               N, self.stem.H, self.stem.W, self.cin, self.f, st,
+               nbytes=N * self.stem.H * self.stem.W * self.cin * (4 + self.f * es))
         if bucket_hook:
             bucket_hook("inc.double_conv.0")
         if side is not None:

@@ -155,7 +155,46 @@ def case_ssim_windows():
     print("ssim_windows", [float(rec[f"ssim_w{ws}"]) for ws in (3, 7, 11, 15)])
 
 
+def case_multichannel(tag="unet_f16_c3to2_n2_32x32", cin=3, cout=2, f=16, n=2, h=32, w=32, seed=7):
+    """UNetSuperRes(in_channels=3, out_channels=2) (unet_model.py:129,137,172).  The reference's CombinedLoss builds a
+    one-channel SSIM window (losses.py:184), so its SSIM leg cannot take these outputs: the loss here is its L1 leg
+    (ssim_weight=0) and, separately, 0.6 * L1 + 0.4 * (1 - ssim(...)) through the functional ssim, which builds the window per
+    channel (losses.py:44-47)."""
+    model = UNetSuperRes(cin, cout, f)
+    model.load_state_dict(formula_state_dict(f, seed, in_channels=cin, out_channels=cout))
+    model.train()
+    low = torch.cat([make_pair(n, h, w, seed + 10 * i)[0] for i in range(cin)], 1)
+    high = torch.cat([make_pair(n, h, w, seed + 10 * i)[1] for i in range(cout)], 1)
+    taps, handles = hook_taps(model)
+    out = model(low)
+    for hd in handles:
+        hd.remove()
+    rec = {"low": low.numpy(), "high": high.numpy(), "out": out.detach().numpy(), "meta": np.array([f, n, h, w, seed, cin, cout])}
+    for k, v in taps.items():
+        rec["tap/" + k] = digest(v)
+    for sw in (0.0, 0.4):
+        model.zero_grad(set_to_none=True)
+        o = model(low)
+        if sw == 0.0:
+            loss = CombinedLoss(ssim_weight=0.0, device=torch.device("cpu"))(o, high)
+        else:
+            loss = (1 - sw) * torch.nn.functional.l1_loss(o, high) + sw * (1 - torch.clamp(ssim(o, high), 0, 1))
+        loss.backward()
+        rec[f"loss/{sw}"] = np.float64(loss.item())
+        for k, p in model.named_parameters():
+            g = p.grad.detach()
+            rec[f"grad/{sw}/{k}"] = digest(g) if g.numel() > 512 else g.numpy().copy()
+    rec["ssim_metric"] = np.float64(ssim(out.detach(), high).item())
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **rec)
+    print(tag, "out", tuple(out.shape), "loss0.4", rec.get("loss/0.4"))
+
+
 def main():
+    if "--only-multichannel" in sys.argv:       # (added in round 3: leaves the earlier fixtures byte-identical)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        case_multichannel()
+        return
     if "--only-ssim-windows" in sys.argv:       # (added in round 3: leaves the earlier fixtures byte-identical)
         torch.manual_seed(0)
         torch.set_num_threads(8)
@@ -170,6 +209,7 @@ def main():
     case_forward_backward("unet_f32_n1_64x64", 32, 1, 64, 64, seed=5, ssim_ws=(0.4,))
     case_ssim()
     case_ssim_windows()
+    case_multichannel()
     case_train3()
     case_train3(ssim_weight=0.0, tag="train3_l1")
 

@@ -453,6 +453,57 @@ def test_head_forward_backward(dt):
     assert U.relerr(db.cpu(), br.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("cin", [2, 3, 4])
+def test_stem_multichannel_forward_and_wgrad(dt, cin):
+    """nn.Conv2d(in_channels, f, 3) of `inc` for in_channels > 1 (unet_model.py:29,137): x NCHW, weights [Cout][9][Cin]."""
+    n, cout, h, w = 2, 32, 19, 45
+    x, wt = torch.rand(n, cin, h, w, generator=torch.Generator().manual_seed(50)), rnd(cout, cin, 3, 3, seed=51)
+    xd, wd = x.to(U.DEV).contiguous(), wt.permute(0, 2, 3, 1).contiguous().to(U.DEV)
+    out = torch.empty((n, h, w, cout), dtype=U.tdt(dt), device=U.DEV)
+    stats = torch.zeros(L.STAT_SLOTS * n * 16, dtype=torch.float64, device=U.DEV)
+    L.call("mrisr_stem_forward_multi", dt, xd.data_ptr(), wd.data_ptr(), out.data_ptr(), stats.data_ptr(), n, h, w, cin, cout, 8, U.stream())
+    ref = F.conv2d(x, wt, padding=1)
+    assert U.relerr(U.nchw(out), ref) <= TOL_OUT[dt]
+    o = U.nchw(out).view(n, 8, cout // 8, h, w).double()
+    assert torch.allclose(stats.cpu().view(L.STAT_SLOTS, n, 8, 2).sum(0)[..., 1], (o * o).sum((2, 3, 4)), rtol=1e-4)
+    dy = rnd(n, cout, h, w, seed=52)
+    dw = torch.zeros(cout * 9 * cin, dtype=torch.float32, device=U.DEV)
+    L.call("mrisr_stem_wgrad_multi", dt, xd.data_ptr(), U.nhwc(dy, dt).data_ptr(), dw.data_ptr(), n, h, w, cin, cout, U.stream())
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(x, wr, padding=1).backward(U.rounded(dy, dt))
+    assert U.relerr(dw.cpu().view(cout, 3, 3, cin).permute(0, 3, 1, 2), wr.grad) <= TOL_F32[dt]
+    assert L.load().mrisr_stem_forward_multi(dt, xd.data_ptr(), wd.data_ptr(), out.data_ptr(), None, n, h, w, 5, cout, 8, U.stream()) != 0
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_head_multichannel_forward_backward(dt, k):
+    """GroupNorm + LeakyReLU -> nn.Conv2d(f/2, out_channels, 1) + bias -> sigmoid for out_channels > 1 (unet_model.py:172,211)."""
+    n, c, h, w = 2, 16, 23, 41
+    x = rnd(n, c, h, w, seed=60)
+    sc, sh = gn_affine(n, c, 61)
+    wt, b = rnd(k, c, seed=62, scale=0.3), rnd(k, seed=64, scale=0.2)
+    xd, scd, shd, wd, bd = U.nhwc(x, dt), sc.to(U.DEV), sh.to(U.DEV), wt.to(U.DEV), b.to(U.DEV)
+    out = torch.empty((n, k, h, w), dtype=torch.float32, device=U.DEV)
+    L.call("mrisr_head_forward_multi", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+           n, h, w, c, k, U.stream())
+    act = F.leaky_relu(U.rounded(x, dt) * sc.view(n, c, 1, 1) + sh.view(n, c, 1, 1), 0.2).requires_grad_(True)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.sigmoid(F.conv2d(act, wr.view(k, c, 1, 1), br))
+    assert U.relerr(out.cpu(), ref.detach()) <= 1e-5
+    dout = rnd(n, k, h, w, seed=63)
+    ref.backward(dout)
+    da = torch.empty((n, h, w, c), dtype=U.tdt(dt), device=U.DEV)
+    dw, db = torch.zeros(k, c, device=U.DEV), torch.zeros(k, device=U.DEV)
+    doutd = dout.to(U.DEV)
+    L.call("mrisr_head_backward_multi", dt, xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wd.data_ptr(), out.data_ptr(),
+           doutd.data_ptr(), da.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, w, c, k, U.stream())
+    assert U.relerr(U.nchw(da), act.grad) <= TOL_OUT[dt]
+    assert U.relerr(dw.cpu(), wr.grad) <= 1e-4
+    assert U.relerr(db.cpu(), br.grad) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------- GN backward
 def _gn_forward_state(x, gamma, beta, dt):
     """Runs stats -> gn_finalize on the device for x (N,C,H,W); returns device tensors."""

@@ -99,6 +99,70 @@ def test_loss_and_gradients_fp32(golden_dir, case, ssim_weight):
     _report(f"grads fp32 {case} ssim_w={ssim_weight}: loss err {abs(loss.item() - float(ref_loss)):.2e}, worst grad rel err {worst:.2e}")
 
 
+def _multichannel(golden_dir):
+    g = _golden(golden_dir, "unet_f16_c3to2_n2_32x32")
+    f, n, h, w, seed, cin, cout = (int(v) for v in g["meta"])
+    sd = formula_state_dict(f, seed, in_channels=cin, out_channels=cout)
+    return g, f, cin, cout, sd, torch.from_numpy(g["low"]), torch.from_numpy(g["high"])
+
+
+def test_multichannel_forward_and_gradients_fp32(golden_dir):
+    """UNetSuperRes(in_channels=3, out_channels=2) (unet_model.py:129,137,172) against the reference's own outputs and losses
+    (golden, fp32 gates of the 1 -> 1 cases) and the oracle's gradients (pinned to the reference's on the CPU,
+    test_oracle_golden.py)."""
+    g, f, cin, cout, sd, low, high = _multichannel(golden_dir)
+    m = UNetSuperRes(cin, cout, f)
+    m.load_state_dict(sd)
+    m = m.cuda().set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        out = m.eval()(low.cuda()).cpu()
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape
+    assert ((out - ref).abs() / ref.abs().clamp_min(1e-3)).max().item() <= 1e-3 and (out - ref).abs().max().item() <= 5e-5
+    assert abs(ssim(out.cuda(), high.cuda()).item() - float(g["ssim_metric"])) <= 1e-5
+    for sw in (0.0, 0.4):
+        _, ref_loss, ref_grads = loss_and_grads(sd, low, high, sw)
+        assert abs(float(ref_loss) - float(g[f"loss/{sw}"])) <= 2e-6
+        m.train()
+        m.zero_grad(set_to_none=True)
+        loss = CombinedLoss(ssim_weight=sw, device=torch.device("cuda"))(m(low.cuda()), high.cuda())
+        loss.backward()
+        assert abs(loss.item() - float(g[f"loss/{sw}"])) <= 2e-5
+        worst = 0.0
+        for k, p in m.named_parameters():
+            r = ref_grads[k]
+            err = (p.grad.cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-7)
+            worst = max(worst, err)
+            assert err <= 5e-4, f"{k}: rel err {err:.3e}"
+        _report(f"grads fp32 multichannel {cin}->{cout} ssim_w={sw}: worst grad rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_multichannel_16bit(golden_dir, dtype):
+    g, f, cin, cout, sd, low, high = _multichannel(golden_dir)
+    m = UNetSuperRes(cin, cout, f)
+    m.load_state_dict(sd)
+    m = m.cuda().set_compute_dtype(dtype)
+    with torch.no_grad():
+        out = m.eval()(low.cuda()).cpu()
+    ref = torch.from_numpy(g["out"])
+    a, b = losses_ref.psnr(out, high), losses_ref.psnr(ref, high)
+    assert abs(a - b) <= 5e-3 * abs(b), (a, b)
+    assert losses_ref.psnr(out, ref) >= 35.0 and float(losses_ref.ssim(out, ref)) >= 0.99
+    _, ref_loss, ref_grads = loss_and_grads(sd, low, high, 0.4)
+    m.train()
+    scale = 1024.0 if dtype == torch.float16 else 1.0
+    loss = CombinedLoss(ssim_weight=0.4, device=torch.device("cuda"))(m(low.cuda()), high.cuda())
+    (loss * scale).backward()
+    assert abs(loss.item() - float(ref_loss)) <= 5e-3 * float(ref_loss)
+    from oracle.bf16_emul import cos_ratio
+    for k, p in m.named_parameters():
+        if p.numel() < 64:
+            continue                    # (single cancelling sums, see test_gradients_bf16_close)
+        cos, ratio = cos_ratio(p.grad.cpu() / scale, ref_grads[k])
+        assert cos >= 0.90 and abs(ratio - 1.0) <= 0.25, f"{k}: cosine {cos:.4f} norm ratio {ratio:.3f}"
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_gradients_bf16_close(golden_dir, seed):
     """bf16 path vs the fp32 oracle.  Gate: cosine >= 0.95 and |norm ratio - 1| <= 0.10, widened per parameter by what

@@ -103,6 +103,43 @@ def test_ssim_window_sizes_and_both_gradients_match_reference(golden_dir, ws):
         assert np.abs(got.numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+def _multichannel_inputs(g):
+    f, n, h, w, seed, cin, cout = (int(v) for v in g["meta"])
+    low = torch.cat([make_pair(n, h, w, seed + 10 * i)[0] for i in range(cin)], 1)
+    high = torch.cat([make_pair(n, h, w, seed + 10 * i)[1] for i in range(cout)], 1)
+    assert np.array_equal(low.numpy(), g["low"]) and np.array_equal(high.numpy(), g["high"])
+    return f, seed, cin, cout, low, high
+
+
+def test_multichannel_forward_loss_and_grads_match_reference(golden_dir):
+    """UNetSuperRes(in_channels=3, out_channels=2) (unet_model.py:129,137,172): the oracle against the reference's outputs, its
+    L1 loss and 0.6 L1 + 0.4 (1 - ssim) with the per-channel window (tests/golden/unet_f16_c3to2_n2_32x32.npz, written by
+    oracle/gen_golden.py --only-multichannel)."""
+    g = _load(golden_dir, "unet_f16_c3to2_n2_32x32")
+    f, seed, cin, cout, low, high = _multichannel_inputs(g)
+    sd = formula_state_dict(f, seed, in_channels=cin, out_channels=cout)
+    taps = {}
+    out = unet_forward(sd, low, taps)
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape == (low.shape[0], cout, 2 * low.shape[2], 2 * low.shape[3])
+    assert (out - ref).abs().max().item() <= 1e-6
+    for key in g.files:
+        if key.startswith("tap/"):
+            ok, msg = digest_close(taps[key[4:]], g[key], rtol=1e-5)
+            assert ok, f"{key}: {msg}"
+    assert abs(float(ssim(out, high)) - float(g["ssim_metric"])) <= 2e-6
+    for sw in (0.0, 0.4):
+        _, loss, grads = loss_and_grads(sd, low, high, ssim_weight=sw)
+        assert abs(float(loss) - float(g[f"loss/{sw}"])) <= 2e-6
+        for k, gr in grads.items():
+            ref = g[f"grad/{sw}/{k}"]
+            if gr.numel() > 512:
+                ok, msg = digest_close(gr, ref, rtol=2e-4)
+                assert ok, f"{k}: {msg}"
+            else:
+                assert np.abs(gr.numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12) + 1e-9, k
+
+
 @pytest.mark.parametrize("name", ["train3", "train3_l1"])
 def test_train3_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
