@@ -5,7 +5,7 @@ Inside ``UNetSuperRes`` the sub-modules below only HOLD parameters (so that ``na
 ``state_dict`` / ``load_state_dict`` / ``nn.init`` behave exactly as for the reference); all arithmetic
 of ``UNetSuperRes.forward`` runs in hand-written HIP kernels scheduled by
 ``mri_superresolution_amd.engine.UNetEngine``.  Called on their own, the blocks run the same kernels
-layer by layer (``mri_superresolution_amd.standalone``, inference only).  There is no CPU path: calling
+layer by layer (``mri_superresolution_amd.standalone``, forward and backward).  There is no CPU path: calling
 ``forward`` with a CPU tensor, or without the built ``libmrisr.so``, raises.
 
 Parameter storage: all 64 tensors are views of ONE flat fp32 buffer (``model.flat_params``); conv
