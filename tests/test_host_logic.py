@@ -31,6 +31,43 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.GnBwdFin) == 80
 
 
+def test_header_is_plain_c_and_a_c_program_binds_the_library(tmp_path):
+    """The drop-in boundary from the C side: include/mrisr.h compiles as C99 (no C++, no torch types), a C program linked against
+    libmrisr.so calls through it, and the struct layouts gcc computes are the ones the ctypes mirror (_lib.py) declares."""
+    import shutil
+    import subprocess
+    from mri_superresolution_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "bind.c"
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "mrisr.h"
+int main(void) {
+    printf("%d %zu %zu %zu %zu %zu %zu %zu %zu\\n", mrisr_version(), sizeof(mrisr_src), sizeof(mrisr_conv_desc), sizeof(mrisr_pack_job),
+           sizeof(mrisr_consumer), sizeof(mrisr_gn_bwd_fin), sizeof(mrisr_aug_geo), sizeof(mrisr_aug_photo), offsetof(mrisr_conv_desc, src));
+    /* argument validation needs no GPU: a null descriptor is refused with MRISR_E_ARG and a message */
+    int rc = mrisr_conv_forward(NULL, NULL);
+    printf("%d %s\\n", rc, mrisr_last_error());
+    return 0;
+}
+''')
+    exe = tmp_path / "bind"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    v = [int(t) for t in out[0].split()]
+    assert v[0] == _lib.ABI_VERSION
+    assert v[1:8] == [ctypes.sizeof(t) for t in (_lib.Src, _lib.ConvDesc, _lib.PackJob, _lib.Consumer, _lib.GnBwdFin,
+                                                 _lib.AugGeo, _lib.AugPhoto)]
+    assert v[8] == _lib.ConvDesc.src.offset
+    rc, msg = out[1].split(" ", 1)
+    assert int(rc) == -1 and "null" in msg
+
+
 def test_module_contract_matches_reference_spec():
     from mri_superresolution_amd.models.unet_model import UNet, UNetSuperRes, DoubleConv, Down, Up, PixelShuffleUp, icnr
     from oracle.unet_ref import formula_state_dict, state_dict_spec
