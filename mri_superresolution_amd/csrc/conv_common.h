@@ -50,11 +50,12 @@ static inline int conv_wgrad_fast(int dtype, int loader, int ks, int tw_log2, in
     return 4 / (nfo * nfi);
 }
 // output-channel block of the ring weight layout (csrc/conv_ring.hip, csrc/conv_pc.hip) for an operand, 0 = no such image
-// (128-channel blocks; one 32-channel block for the 32-channel layer of the 2x head)
+// (128-channel blocks, else 64-channel blocks; one 32-channel block for the 32-channel layer of the 2x head)
 __host__ __device__ static inline int conv_ring_bn(int dtype, int Cout, int Cin, int ksize) {
     if (dtype != MRISR_BF16 && dtype != MRISR_F16) return 0;
     if (ksize != 3 || Cin % 16) return 0;
     if (Cout % 128 == 0) return 128;
+    if (Cout % 64 == 0) return 64;                 // conv_pc.hip's tall-tile variant
     return Cout == 32 ? 32 : 0;
 }
 static inline int conv_choose_bn(int Cout) { return Cout >= 64 ? 64 : 32; }

@@ -1377,6 +1377,7 @@ bool conv_wgrad_rows_ok(const mrisr_conv_desc* d);
 int launch_conv_ring(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
 // conv_pc.hip: producer / consumer waves (GroupNorm or stored sources, 128-channel output blocks)
 bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p);
+int conv_pc_kind(const mrisr_conv_desc* d, const ConvParams& p);
 int launch_conv_pc(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s);
 // conv1x1.hip: 1x1 convolutions as a plain GEMM
 bool conv1x1_gemm_eligible(const mrisr_conv_desc* d, const ConvParams& p);
@@ -1492,7 +1493,8 @@ extern "C" int mrisr_conv_variant(const mrisr_conv_desc* d, int wgrad, char* out
     } else if (conv_ring_eligible(d, p)) {
         snprintf(out, n, "conv_ring_kernel<%s,2,4>", t);
     } else if (conv_pc_eligible(d, p)) {
-        snprintf(out, n, "conv_pc_kernel<%s,%d>", t, d->src[0].mode == MRISR_SRC_NORM ? 1 : 0);
+        // (",64": the 64-channel blocks on tall tiles)
+        snprintf(out, n, "conv_pc_kernel<%s,%d%s>", t, d->src[0].mode == MRISR_SRC_NORM ? 1 : 0, conv_pc_kind(d, p) == 2 ? ",64" : "");
     } else if (conv1x1_gemm_eligible(d, p)) {
         snprintf(out, n, "conv1x1_gemm_kernel<%s,%d>", t, d->src[0].mode == MRISR_SRC_NORM ? 1 : 0);
     } else {

@@ -52,15 +52,20 @@ constexpr int kPcThreads = 512;                  // 4 MFMA waves + 4 staging wav
 constexpr int pc_np(bool blend) { return blend ? 4 : 4; }
 constexpr int pc_threads(bool blend) { return 256 + 64 * pc_np(blend); }
 constexpr int kPcBN = 128;                       // output channels per workgroup (NI = 4; the narrow variant NI = 1 owns 32)
-constexpr int kPcHaloW = 34, kPcHaloH = 10, kPcHaloRows = kPcHaloW * kPcHaloH;     // 8 x 32 pixel tile + halo
+// pixel tile = (4 mi) x 32: an MFMA wave owns mi rows of 32 pixels (mi = 2: 8 x 32 tile, 10 x 34 halo; mi = 4: the tall tile of
+// the 64-channel variant, 18 x 34 halo)
+constexpr int kPcHaloW = 34;
+constexpr int pc_halo_h(int mi) { return 4 * mi + 2; }
+constexpr int pc_halo_rows(int mi) { return kPcHaloW * pc_halo_h(mi); }
 // 16-byte vectors per staging thread: 340 halo rows x 2 over 64 np threads (the last slot stores unpredicated: whole slots of room)
-constexpr int pc_hslots(int np) { return (2 * kPcHaloRows + 64 * np - 1) / (64 * np); }
-constexpr int pc_hbytes(int np) { return pc_hslots(np) * 64 * np * 16; }
+constexpr int pc_hslots(int np, int mi = 2) { return (2 * pc_halo_rows(mi) + 64 * np - 1) / (64 * np); }
+constexpr int pc_hbytes(int np, int mi = 2) { return pc_hslots(np, mi) * 64 * np * 16; }
 constexpr int pc_wbytes(int ni) { return 9 * 32 * ni * 32; }                     // weight image of one (cout block, cin chunk)
 constexpr int pc_wslots(int ni, int np) { return (pc_wbytes(ni) / 16 + 64 * np - 1) / (64 * np); }
-constexpr int pc_buf(int ni, int np) { return pc_hbytes(np) + pc_wslots(ni, np) * 64 * np * 16; }
+constexpr int pc_buf(int ni, int np, int mi = 2) { return pc_hbytes(np, mi) + pc_wslots(ni, np) * 64 * np * 16; }
 constexpr int kPcStages = 3;                     // LDS item buffers (3 x 48 KiB at NI = 4)
-constexpr int pc_lds(int ni, int np) { return kPcStages * pc_buf(ni, np) + kPcBN * 4 + 64; }   // + bias table + the item counters
+constexpr int pc_lds(int ni, int np, int mi = 2) { return kPcStages * pc_buf(ni, np, mi) + kPcBN * 4 + 64; }   // + bias table + the item counters
+constexpr unsigned pc_slot_ones(int slots) { return slots <= 0 ? 0u : (pc_slot_ones(slots - 1) | (1u << (4 * (slots - 1)))); }
 
 // Item counters in LDS instead of workgroup barriers: the staging waves may run up to two items ahead of the MFMA waves
 // (they keep staging while a tile's epilogue runs) and nobody waits for the slowest wave of the OTHER role at every item.
@@ -109,15 +114,19 @@ __device__ __forceinline__ void pc_wait_ge(const unsigned* cnt, u32x4 seen, int 
 // NI = 32-channel fragments per MFMA wave (4: 128 output channels per workgroup; 1: the 32-channel layer of the 2x head);
 // BLEND: the input is sigmoid(alpha) * act(src0) + (1 - sigmoid(alpha)) * act(src1) (unet_model.py:206-207), formed by the
 // staging waves - the blended tensor never goes to HBM (eval forward of final_conv.0)
-template <typename T, bool NORM, bool STATS, int NI = 4, bool BLEND = false>
+// MI = 32-pixel rows per MFMA wave.  (NI, MI) = (4, 2): 8 x 32 pixels x 128 channels; (2, 4): 16 x 32 pixels x 64 channels - the
+// 64-channel layers: the same 8 accumulators and 6 fragment reads per 8 MFMAs, 38 instead of 47 KiB staged per item
+template <typename T, bool NORM, bool STATS, int NI = 4, bool BLEND = false, int MI = 2>
 __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const ConvParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams p = pin_params(p_in);
     typedef typename Frag16<T>::type frag_t;
-    constexpr int MI = 2, BN = 32 * NI, VEC = 8;
+    constexpr int BN = 32 * NI, VEC = 8;
     constexpr int NP = pc_np(BLEND), PT = 64 * NP;                  // staging waves / threads
-    constexpr int kPcHaloSlots = pc_hslots(NP), kPcHaloBytes = pc_hbytes(NP);
-    constexpr int kPcWBytes = pc_wbytes(NI), kPcWSlots = pc_wslots(NI, NP), kPcBuf = pc_buf(NI, NP);
+    constexpr int TR = 4 * MI, kPcHaloH = pc_halo_h(MI), kPcHaloRows = pc_halo_rows(MI);      // tile rows, halo rows
+    constexpr int kPcHaloSlots = pc_hslots(NP, MI), kPcHaloBytes = pc_hbytes(NP, MI);
+    constexpr int kPcWBytes = pc_wbytes(NI), kPcWSlots = pc_wslots(NI, NP), kPcBuf = pc_buf(NI, NP, MI);
+    static_assert(kPcHaloSlots <= 8 && kPcHaloRows + PT / 2 < 1000, "edge flags: 4 bits per slot; row / 34 by multiplication");
     static_assert(!BLEND || NORM, "the blend is of two activated sources");
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
         const int tx = tile % p.tiles_x;
         const int r = tile / p.tiles_x;
         n = r / p.tiles_y;
-        ty0 = (r - n * p.tiles_y) * 8;
+        ty0 = (r - n * p.tiles_y) * TR;
         tx0 = tx * 32;
     };
 
@@ -158,8 +167,8 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
         tx0 += 32;
         if (tx0 == p.tiles_x * 32) {
             tx0 = 0;
-            ty0 += 8;
-            if (ty0 == p.tiles_y * 8) { ty0 = 0; ++n; }
+            ty0 += TR;
+            if (ty0 == p.tiles_y * TR) { ty0 = 0; ++n; }
         }
     };
 
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
                     const bool ring_only = ys0 >= -1 && xs0 >= -1 && ys0 + kPcHaloH <= Hs + 1 && xs0 + kPcHaloW <= Ws + 1;
                     if (ring_only) {
                         const unsigned tm = (ys0 < 0 ? 1u : 0u) | (ys0 + kPcHaloH > Hs ? 2u : 0u) | (xs0 < 0 ? 4u : 0u) | (xs0 + kPcHaloW > Ws ? 8u : 0u);
-                        hit = fflags & (tm * 0x111u);
+                        hit = fflags & (tm * pc_slot_ones(kPcHaloSlots));
                     } else {
 #pragma unroll
                         for (int j = 0; j < kPcHaloSlots; ++j) {
@@ -408,13 +417,17 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
     // GroupNorm partial sums per lane: a group spans >= 16 channels here (host-checked), i.e. the quad pairs {0,1} and {2,3}
     // of a fragment each lie in one group
     // (NI = 1, the 32-channel layer: groups of 4 channels = one quad each -> one accumulator per quad)
-    constexpr int QSH = NI == 1 ? 0 : 1;            // quads per accumulator = 1 << QSH
+    constexpr int QSH = NI == 4 ? 1 : 0;            // quads per accumulator = 1 << QSH (the 64-channel layers: groups of 8 = one quad of both lane halves)
     constexpr int NSQ = STATS ? (4 >> QSH) : 1;
-    pc_f32x2 st_s[NI][NSQ], st_ss[NI][NSQ];       // pairs: v_pk_add_f32 / v_pk_fma_f32 straight from the accumulator registers
+    // pairs: v_pk_add_f32 / v_pk_fma_f32 straight from the accumulator registers (the tall variant: single floats - its 16 pixel-
+    // fragment registers more leave no room for 32 statistics registers)
+    constexpr bool ST1 = MI > 2;
+    typedef typename std::conditional<ST1, float, pc_f32x2>::type st_t;
+    st_t st_s[NI][NSQ], st_ss[NI][NSQ];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int q = 0; q < NSQ; ++q) { st_s[ni][q] = pc_f32x2{0.f, 0.f}; st_ss[ni][q] = pc_f32x2{0.f, 0.f}; }
+        for (int q = 0; q < NSQ; ++q) { st_s[ni][q] = st_t{}; st_ss[ni][q] = st_t{}; }
 
     // epilogue of a finished tile (as conv_ring.hip): bias / ReLU, GroupNorm partial sums, packed 16-bit values exchanged
     // between the lane halves (permlane32) -> 16-byte stores.  Whole tiles only (host-checked): no predication.
@@ -448,7 +461,10 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
                         v[j] = acc[ni][mi][4 * q + j];
                         acc[ni][mi][4 * q + j] = 0.f;
                     }
-                    if (STATS) {
+                    if constexpr (STATS && ST1) {
+                        st_s[ni][q >> QSH] += (v[0] + v[1]) + (v[2] + v[3]);
+                        st_ss[ni][q >> QSH] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], st_ss[ni][q >> QSH]))));
+                    } else if constexpr (STATS) {
                         const pc_f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
                         st_s[ni][q >> QSH] += v01;
                         st_s[ni][q >> QSH] += v23;
@@ -479,15 +495,17 @@ __global__ __launch_bounds__(pc_threads(BLEND), 2) void conv_pc_kernel(const Con
             for (int q = 0; q < NSQ; ++q) {
                 int co = bn0 + ni * 32 + (16 >> (1 - QSH)) * q + 4 * lh;
                 asm volatile("" : "+v"(co));
-                const float s = half_wave_sum(st_s[ni][q][0] + st_s[ni][q][1]), ss = half_wave_sum(st_ss[ni][q][0] + st_ss[ni][q][1]);
+                float s, ss;
+                if constexpr (ST1) { s = half_wave_sum(st_s[ni][q]); ss = half_wave_sum(st_ss[ni][q]); }
+                else { s = half_wave_sum(st_s[ni][q][0] + st_s[ni][q][1]); ss = half_wave_sum(st_ss[ni][q][0] + st_ss[ni][q][1]); }
                 if (lr == 0) {
                     const int g = co / gs;
                     double* sp = p.stats + stat_slot_off_id(bid, p.N, p.groups) + ((size_t)n * p.groups + g) * 2;
                     atomic_add_f64(sp, (double)s);
                     atomic_add_f64(sp + 1, (double)ss);
                 }
-                st_s[ni][q] = pc_f32x2{0.f, 0.f};
-                st_ss[ni][q] = pc_f32x2{0.f, 0.f};
+                st_s[ni][q] = st_t{};
+                st_ss[ni][q] = st_t{};
             }
     };
 
@@ -563,7 +581,8 @@ extern "C" int mrisr_debug_phase_cycles(unsigned long long* out96) {
 #endif
 
 // Does this launch take the producer / consumer kernel?  (p: filled by conv_fill_params.)
-// 0 = no, 4 = 128-channel blocks, 1 = the narrow blend variant (Cout = 32, two activated sources blended by the staging waves)
+// 0 = no, 4 = 128-channel blocks, 2 = 64-channel blocks on tall tiles, 1 = the narrow blend variant (Cout = 32, two activated
+// sources blended by the staging waves)
 int conv_pc_kind(const mrisr_conv_desc* d, const ConvParams& p) {
 #ifdef MRISR_NO_PC
     return 0;
@@ -581,6 +600,17 @@ int conv_pc_kind(const mrisr_conv_desc* d, const ConvParams& p) {
         if ((unsigned long long)d->N * d->src[i].H * d->src[i].W * d->src[i].C * 2ull >= (1ull << 31)) return 0;
     if (d->H % 8 || d->W % 32) return 0;                            // whole 8 x 32 tiles only (unpredicated stores)
     const int tiles = d->N * (d->H / 8) * (d->W / 32);
+    if (d->combine == MRISR_COMBINE_CONCAT && d->Cout % kPcBN && d->Cout % 64 == 0) {
+        // 64-channel blocks on tall tiles (16 x 32 pixels): the 64-channel layers and the input gradients that end in 64 channels
+#ifdef MRISR_NO_PC64
+        return 0;
+#endif
+        if (d->H % 16) return 0;
+        if (d->nsrc == 2 && (d->src[0].C % 16)) return 0;
+        if (d->src[0].mode == MRISR_SRC_RAW && d->Cin < 128) return 0;  // (64 -> 64 input gradient at 256^2: 111 vs 101 us on the LDS-DMA kernel)
+        if (d->stats && ((d->Cout / d->groups) & 3)) return 0;      // a GroupNorm group spans whole accumulator quads
+        return (long)(tiles / 2) * (d->Cout / 64) * 4 >= (long)p.cus * 3 ? 2 : 0;
+    }
     if (d->combine == MRISR_COMBINE_BLEND) {
         // final_conv.0 without the materialised blend (eval forward): 32 output channels, two activated sources of the conv's
         // own geometry; GroupNorm groups of 4 channels = one accumulator quad each
@@ -601,23 +631,24 @@ int conv_pc_kind(const mrisr_conv_desc* d, const ConvParams& p) {
 }
 bool conv_pc_eligible(const mrisr_conv_desc* d, const ConvParams& p) { return conv_pc_kind(d, p) != 0; }
 
-template <typename T, bool NORM, bool STATS, int NI, bool BLEND>
+template <typename T, bool NORM, bool STATS, int NI, bool BLEND, int MI = 2>
 static void launch_pc_k(const ConvParams& p, int grid, hipStream_t s) {
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, NORM, STATS, NI, BLEND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<T, NORM, STATS, NI, BLEND, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL((conv_pc_kernel<T, NORM, STATS, NI, BLEND>), dim3(grid), dim3(pc_threads(BLEND)), pc_lds(NI, pc_np(BLEND)), s, p);
+    hipLaunchKernelGGL((conv_pc_kernel<T, NORM, STATS, NI, BLEND, MI>), dim3(grid), dim3(pc_threads(BLEND)), pc_lds(NI, pc_np(BLEND), MI), s, p);
 }
 
 template <typename T>
 static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s) {
     const int kind = conv_pc_kind(d, cp);
-    const int bn = kind == 1 ? 32 : kPcBN;
+    const int bn = kind == 1 ? 32 : kind == 2 ? 64 : kPcBN;
+    const int tr = kind == 2 ? 16 : 8;
     ConvParams p = cp;
     p.wpacked = d->wpacked_ring;
     p.nchunks = d->Cin / 16; p.ncb = d->Cout / bn;
-    p.tiles_x = d->W / 32; p.tiles_y = d->H / 8;
+    p.tiles_x = d->W / 32; p.tiles_y = d->H / tr;
     p.ntiles = d->N * p.tiles_x * p.tiles_y;
     p.groups = d->stats ? d->groups : 0;
     int per_cb = cp.cus / p.ncb;
@@ -630,6 +661,11 @@ static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream
     if (kind == 1) {
         if (stats) launch_pc_k<T, true, true, 1, true>(p, grid, s);
         else launch_pc_k<T, true, false, 1, true>(p, grid, s);
+    } else if (kind == 2) {
+        if (norm && stats) launch_pc_k<T, true, true, 2, false, 4>(p, grid, s);
+        else if (norm) launch_pc_k<T, true, false, 2, false, 4>(p, grid, s);
+        else if (stats) launch_pc_k<T, false, true, 2, false, 4>(p, grid, s);
+        else launch_pc_k<T, false, false, 2, false, 4>(p, grid, s);
     } else if (norm && stats) launch_pc_k<T, true, true, 4, false>(p, grid, s);
     else if (norm) launch_pc_k<T, true, false, 4, false>(p, grid, s);
     else if (stats) launch_pc_k<T, false, true, 4, false>(p, grid, s);

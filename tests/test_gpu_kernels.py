@@ -153,9 +153,26 @@ def test_conv_pc_producer_consumer(dt, case):
     concat with the second source smaller and offset (unet_model.py:86-92; chunks switch source at 48 channels);
     raw_bias_relu: stored source, bias + ReLU epilogue, no statistics (input-gradient / VGG form); raw_odd_items: an odd item
     count per workgroup (the staging loop's padding half); half_chip: grid sized by cu_limit."""
-    n, cins, cout, h, w = {"norm": (8, (64,), 128, 64, 96), "norm_multi_tile": (13, (32,), 256, 40, 96),
-                           "norm_concat_pad": (8, (48, 32), 128, 64, 96), "raw_bias_relu": (8, (144,), 256, 64, 96),
-                           "raw_odd_items": (3, (176,), 128, 40, 32), "half_chip": (8, (64,), 128, 64, 96)}[case]
+    _conv_pc_case(dt, case, {"norm": (8, (64,), 128, 64, 96), "norm_multi_tile": (13, (32,), 256, 40, 96),
+                             "norm_concat_pad": (8, (48, 32), 128, 64, 96), "raw_bias_relu": (8, (144,), 256, 64, 96),
+                             "raw_odd_items": (3, (176,), 128, 40, 32), "half_chip": (8, (64,), 128, 64, 96)}[case], "conv_pc_kernel<")
+
+
+@pytest.mark.parametrize("dt", [L.BF16, L.F16])
+@pytest.mark.parametrize("case", ["norm", "norm_multi_tile", "norm_concat_pad", "raw_bias_relu", "raw_odd_items", "half_chip", "norm_192"])
+def test_conv_pc_tall_tiles_64_channel_blocks(dt, case):
+    """The (NI, MI) = (2, 4) instantiation of csrc/conv_pc.hip: 16 x 32 pixels x 64 output channels per item, for output widths
+    that are a multiple of 64 but not of 128 (the 64-channel layers of the network and the input gradients that end in 64
+    channels).  Same cases as above on planes of whole 16 x 32 tiles; GroupNorm groups of 8 channels = one accumulator quad of
+    both lane halves; norm_192: three 64-channel blocks."""
+    _conv_pc_case(dt, case, {"norm": (8, (64,), 64, 128, 96), "norm_multi_tile": (13, (32,), 64, 80, 96),
+                             "norm_concat_pad": (8, (48, 32), 64, 128, 96), "raw_bias_relu": (8, (144,), 64, 128, 96),
+                             "raw_odd_items": (3, (176,), 64, 80, 32), "half_chip": (8, (64,), 64, 128, 96),
+                             "norm_192": (6, (32,), 192, 64, 96)}[case], "conv_pc_kernel<", ",64>")
+
+
+def _conv_pc_case(dt, case, shape, prefix, suffix=">"):
+    n, cins, cout, h, w = shape
     cin = sum(cins)
     wt = rnd(cout, cin, 3, 3, seed=52, scale=0.1)
     norm = case.startswith("norm") or case == "half_chip"
@@ -171,12 +188,12 @@ def test_conv_pc_producer_consumer(dt, case):
     bias = rnd(cout, seed=57) if case == "raw_bias_relu" else None
     ran = []
     kw = dict(bias=bias, with_stats=case != "raw_bias_relu", variant=ran)
-    if case in ("half_chip", "raw_odd_items"):
-        kw["cu_limit"] = 128 if case == "half_chip" else 16
+    if case in ("half_chip", "raw_odd_items", "norm_multi_tile"):
+        kw["cu_limit"] = {"half_chip": 128, "raw_odd_items": 16, "norm_multi_tile": 64}[case]
     if case == "raw_bias_relu":
         kw["relu_out"] = 1
     out, stats = U.conv_forward(dt, srcs, wt, h, w, 3, **kw)
-    assert ran[0].startswith("conv_pc_kernel<"), ran
+    assert ran[0].startswith(prefix) and ran[0].endswith(suffix) and (suffix != ">" or not ran[0].endswith(",64>")), ran
     ref = F.conv2d(U.ref_conv_input(srcs, dt, h, w), U.rounded(wt, dt), bias, padding=1)
     if case == "raw_bias_relu":
         ref = F.relu(ref)
