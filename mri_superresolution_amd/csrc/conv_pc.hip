@@ -644,7 +644,12 @@ template <typename T>
 static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream_t s) {
     const int kind = conv_pc_kind(d, cp);
     const int bn = kind == 1 ? 32 : kind == 2 ? 64 : kPcBN;
-    const int tr = kind == 2 ? 16 : 8;
+#ifdef MRISR_PC_BLEND_SHORT
+    const bool tall_blend = false;
+#else
+    const bool tall_blend = kind == 1 && d->H % 16 == 0;            // the blend variant on tall items: 10 % less halo per pixel
+#endif
+    const int tr = (kind == 2 || tall_blend) ? 16 : 8;
     ConvParams p = cp;
     p.wpacked = d->wpacked_ring;
     p.nchunks = d->Cin / 16; p.ncb = d->Cout / bn;
@@ -658,7 +663,10 @@ static int launch_pc_t(const mrisr_conv_desc* d, const ConvParams& cp, hipStream
     per_cb = ceil_div(p.ntiles, p.tiles_per_block);
     const int grid = per_cb * p.ncb;
     const bool norm = d->src[0].mode == MRISR_SRC_NORM, stats = d->stats != nullptr;
-    if (kind == 1) {
+    if (kind == 1 && tall_blend) {
+        if (stats) launch_pc_k<T, true, true, 1, true, 4>(p, grid, s);
+        else launch_pc_k<T, true, false, 1, true, 4>(p, grid, s);
+    } else if (kind == 1) {
         if (stats) launch_pc_k<T, true, true, 1, true>(p, grid, s);
         else launch_pc_k<T, true, false, 1, true>(p, grid, s);
     } else if (kind == 2) {

@@ -359,7 +359,9 @@ class UNetEngine:
             # eval forward, 16-bit storage: the blend is formed by the staging waves of conv_pc_kernel<..., NI = 1, BLEND> - the
             # blended tensor (268 MB at the headline shapes: 158 us to write it, then read again by the conv) never exists.
             # Training keeps it: the layer's weight gradient reads it.
-            fused_blend = (layer.blend_src and not training and es == 2 and not TUNING.no_fused_blend
+            # (32 output channels: the width conv_pc's blend variant exists for - base_filters = 64; wider models would fall to the
+            # classic blend-loader kernel, which is slower than materialising: C5 eval forward 479 vs 455-465 slices/s)
+            fused_blend = (layer.blend_src and not training and es == 2 and not TUNING.no_fused_blend and layer.cout == 32
                            and (layer.name, dt, 0, "ring") in self._packed)
             if layer.blend_src and not fused_blend:
                 a, b = layer.srcs[0].node, layer.srcs[1].node

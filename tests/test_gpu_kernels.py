@@ -240,13 +240,14 @@ def test_conv1x1_gemm(dt, case):
 
 
 @pytest.mark.parametrize("dt", [L.BF16, L.F16])
-@pytest.mark.parametrize("case", ["head", "two_images_multi_tile"])
+@pytest.mark.parametrize("case", ["head", "two_images_multi_tile", "short_tiles"])
 def test_conv_pc_blend_narrow(dt, case):
     """conv_pc_kernel<..., NI = 1, BLEND>: final_conv.0 of the eval forward (unet_model.py:206-209) - 32 output channels, the input
     sigmoid(alpha) * act(bilinear branch) + (1 - sigmoid(alpha)) * act(pixel-shuffle branch) formed by the staging waves,
     GroupNorm statistics over groups of 4 channels - against torch's conv on the blended activations and against the classic
     blend-loader kernel."""
-    n, h, w = {"head": (8, 64, 96), "two_images_multi_tile": (2, 128, 256)}[case]
+    # (planes of whole 16 x 32 tiles take the tall items, MI = 4; "short_tiles": 72 rows -> the 8 x 32 items)
+    n, h, w = {"head": (8, 64, 96), "two_images_multi_tile": (2, 128, 256), "short_tiles": (8, 72, 96)}[case]
     cin = cout = 32
     wt = rnd(cout, cin, 3, 3, seed=170, scale=0.1)
     alpha = torch.tensor(0.3)
